@@ -1,0 +1,470 @@
+"""TEST INFRASTRUCTURE ONLY -- Python face of the CPU oracle.
+
+Nothing under ``totton-rasp-gpu-dsp_amd/`` may import this module. Allowed
+users: ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg.
+
+Three checkers live here (citations relative to /root/reference):
+
+* ``RefUpsampler`` / ``ref_*``  -- ctypes face of ``oracle/_ref/libref_oracle.so``
+  = the reference's own C++ (CPU fallback of ``VulkanStreamingUpsampler``,
+  ``eq_parser.cpp``, ``eq_to_fir.cpp``) compiled by ``oracle/Makefile``.
+* ``OracleUpsampler``           -- ctypes face of ``oracle/_build/liboracle.so``
+  = our plain-C restatement (``oracle_upsampler.c``), pinned bit-for-bit to the
+  former by ``tests/test_oracle.py``.
+* numpy restatements of the byte/float work that cannot be compiled here
+  (ALSA headers are absent): PCM<->float (``src/alsa/alsa_common.cpp:42-127``),
+  the EQ maths (``src/audio/eq_to_fir.cpp``), the APO parser
+  (``src/audio/eq_parser.cpp:177-259``) and an fp64 "truth" convolution.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+ORACLE_LIB = _HERE / "_build" / "liboracle.so"
+REF_LIB = _HERE / "_ref" / "libref_oracle.so"
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_f64p)
+
+
+# --------------------------------------------------------------------------
+# sidecar reader used by the checkers only (python json; the product has its
+# own C++ parser that mirrors the reference's substring search)
+# --------------------------------------------------------------------------
+def read_filter(json_path: str | os.PathLike):
+    p = Path(json_path)
+    meta = json.loads(p.read_text())
+    binp = Path(meta["coefficients_bin"])
+    if not binp.is_absolute():
+        binp = p.parent / binp
+    h = np.fromfile(binp, dtype="<f4")
+    return h, int(meta["taps"]), int(meta["fft_size"]), int(meta["block_size"]), int(
+        meta.get("upsample_factor", 1)
+    )
+
+
+# --------------------------------------------------------------------------
+# our C restatement
+# --------------------------------------------------------------------------
+_orc = None
+
+
+def oracle_lib():
+    global _orc
+    if _orc is None:
+        if not ORACLE_LIB.exists():
+            raise RuntimeError(f"{ORACLE_LIB} missing: run `make -C oracle`")
+        lib = C.CDLL(str(ORACLE_LIB))
+        lib.orc_fft.argtypes = [_f32p, C.c_size_t, C.c_int]
+        lib.orc_ups_prepare.restype = C.c_void_p
+        lib.orc_ups_prepare.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+        lib.orc_ups_destroy.argtypes = [C.c_void_p]
+        lib.orc_ups_reset.argtypes = [C.c_void_p]
+        lib.orc_ups_get_spectrum.argtypes = [C.c_void_p, _f32p]
+        lib.orc_ups_process.restype = C.c_long
+        lib.orc_ups_process.argtypes = [C.c_void_p, _f32p, C.c_size_t, _f32p]
+        _orc = lib
+    return _orc
+
+
+def oracle_fft(x: np.ndarray, inverse: bool = False) -> np.ndarray:
+    """fp32 recurrence-twiddle radix-2 FFT (fft_utils.h:30-61)."""
+    v = np.ascontiguousarray(x, dtype=np.complex64).copy()
+    oracle_lib().orc_fft(_fp(v.view(np.float32)), v.size, int(inverse))
+    return v
+
+
+class OracleUpsampler:
+    def __init__(self, coeffs, taps, fft, block, factor):
+        self.lib = oracle_lib()
+        h = np.ascontiguousarray(coeffs, dtype=np.float32)
+        assert h.size == taps
+        self.taps, self.fft, self.block, self.factor = taps, fft, block, max(factor, 1)
+        self.h = self.lib.orc_ups_prepare(_fp(h), taps, fft, block, factor)
+        if not self.h:
+            raise ValueError("bad geometry")
+
+    @classmethod
+    def from_json(cls, path):
+        return cls(*read_filter(path))
+
+    def process_block(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.block, dtype=np.float32)
+        n = self.lib.orc_ups_process(self.h, _fp(x), x.size, _fp(out))
+        return out[:n].copy()
+
+    def spectrum(self) -> np.ndarray:
+        out = np.empty(self.fft, dtype=np.complex64)
+        self.lib.orc_ups_get_spectrum(self.h, _fp(out.view(np.float32)))
+        return out
+
+    def reset(self):
+        self.lib.orc_ups_reset(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_ups_destroy(self.h)
+            self.h = None
+
+
+# --------------------------------------------------------------------------
+# the reference itself (compiled)
+# --------------------------------------------------------------------------
+_ref = None
+
+
+def have_ref() -> bool:
+    return REF_LIB.exists()
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        if not REF_LIB.exists():
+            raise RuntimeError(f"{REF_LIB} missing (built only where /root/reference exists)")
+        lib = C.CDLL(str(REF_LIB))
+        lib.ref_ups_create.restype = C.c_void_p
+        lib.ref_ups_destroy.argtypes = [C.c_void_p]
+        lib.ref_ups_clone.restype = C.c_void_p
+        lib.ref_ups_clone.argtypes = [C.c_void_p]
+        lib.ref_ups_load_filter.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.ref_ups_get_config.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
+        lib.ref_ups_process_block.restype = C.c_long
+        lib.ref_ups_process_block.argtypes = [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t]
+        lib.ref_ups_reset.argtypes = [C.c_void_p]
+        lib.ref_fft.argtypes = [_f32p, C.c_size_t, C.c_int]
+        lib.ref_eq_parse.restype = C.c_long
+        lib.ref_eq_parse.argtypes = [C.c_char_p, _f64p, _f64p, C.c_size_t]
+        lib.ref_eq_parse_filter_type.argtypes = [C.c_char_p]
+        lib.ref_eq_filter_type_name.restype = C.c_char_p
+        lib.ref_eq_filter_type_name.argtypes = [C.c_int]
+        lib.ref_eq_biquad.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
+        lib.ref_eq_response.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, _f64p]
+        lib.ref_eq_magnitude.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, _f64p]
+        _ref = lib
+    return _ref
+
+
+class RefUpsampler:
+    """The reference's VulkanStreamingUpsampler (CPU fallback build)."""
+
+    def __init__(self, handle=None):
+        self.lib = ref_lib()
+        self.h = handle or self.lib.ref_ups_create()
+
+    def load_filter(self, path) -> tuple[bool, str]:
+        buf = C.create_string_buffer(1024)
+        ok = self.lib.ref_ups_load_filter(self.h, str(path).encode(), buf, 1024)
+        return bool(ok), buf.value.decode()
+
+    def config(self):
+        v = [C.c_size_t() for _ in range(4)]
+        self.lib.ref_ups_get_config(self.h, *[C.byref(x) for x in v])
+        return tuple(int(x.value) for x in v)
+
+    def process_block(self, x, count=None) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        cap = max(self.config()[2], 1)
+        out = np.empty(cap, dtype=np.float32)
+        n = self.lib.ref_ups_process_block(self.h, _fp(x), x.size if count is None else count, _fp(out), cap)
+        return out[: max(n, 0)].copy()
+
+    def reset(self):
+        self.lib.ref_ups_reset(self.h)
+
+    def clone(self):
+        return RefUpsampler(self.lib.ref_ups_clone(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_ups_destroy(self.h)
+            self.h = None
+
+
+def ref_fft(x, inverse=False):
+    v = np.ascontiguousarray(x, dtype=np.complex64).copy()
+    ref_lib().ref_fft(_fp(v.view(np.float32)), v.size, int(inverse))
+    return v
+
+
+def ref_eq_parse(text: str):
+    bands = np.zeros(9 * 256)
+    pre = C.c_double()
+    n = ref_lib().ref_eq_parse(text.encode(), C.byref(pre), _dp(bands), 256)
+    if n < 0:
+        return None
+    return pre.value, bands[: 9 * n].reshape(n, 9).copy()
+
+
+def ref_eq_response(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    out = np.empty(num_bins, dtype=np.complex128)
+    ref_lib().ref_eq_response(text.encode(), num_bins, full_fft, fs_out, _dp(out.view(np.float64)))
+    return out
+
+
+def ref_eq_magnitude(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    out = np.empty(num_bins)
+    ref_lib().ref_eq_magnitude(text.encode(), num_bins, full_fft, fs_out, _dp(out))
+    return out
+
+
+def ref_eq_biquad(enabled, type_id, freq, gain, q, fs):
+    out = np.empty(5)
+    ref_lib().ref_eq_biquad(int(enabled), int(type_id), freq, gain, q, fs, _dp(out))
+    return out
+
+
+# --------------------------------------------------------------------------
+# fp64 truth: what an exact overlap-save of the same filter must produce.
+# Block b of the stream equals samples [b*B, (b+1)*B) of the linear
+# convolution of the zero-stuffed input with h
+# (tests/cpp/test_vulkan_upsampler.cpp:150-195 checks exactly that).
+# --------------------------------------------------------------------------
+def truth_stream(x: np.ndarray, h: np.ndarray, factor: int, nblocks: int, block: int) -> np.ndarray:
+    from scipy.signal import fftconvolve
+
+    x = np.asarray(x, dtype=np.float64)
+    up = np.zeros(x.size * factor)
+    up[::factor] = x
+    y = fftconvolve(up, np.asarray(h, dtype=np.float64))
+    return y[: nblocks * block].reshape(nblocks, block)
+
+
+# --------------------------------------------------------------------------
+# PCM <-> float (src/alsa/alsa_common.cpp:42-127) -- numpy restatement.
+# ALSA headers are absent so the reference file cannot be compiled here; this
+# restatement is pinned by the reference's round-trip eps
+# (tests/cpp/test_alsa_common.cpp:58-83,153-161) in tests/test_oracle.py.
+# --------------------------------------------------------------------------
+PCM_BYTES = {"s16": 2, "s24": 3, "s32": 4}
+
+
+def parse_format(name: str):
+    """alsa_common.cpp:12-27 (returns canonical short name or None)."""
+    low = name.lower()
+    if low in ("s16", "s16_le"):
+        return "s16"
+    if low in ("s24", "s24_3le"):
+        return "s24"
+    if low in ("s32", "s32_le"):
+        return "s32"
+    return None
+
+
+def pcm_to_float(raw: bytes | np.ndarray, fmt: str) -> np.ndarray:
+    """alsa_common.cpp:42-85: int -> float32 then multiply by 2^-15/-23/-31."""
+    b = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8)
+    if fmt == "s16":
+        return b.view("<i2").astype(np.float32) * np.float32(1.0 / 32768.0)
+    if fmt == "s32":
+        return b.view("<i4").astype(np.float32) * np.float32(1.0 / 2147483648.0)
+    if fmt == "s24":
+        t = b.reshape(-1, 3).astype(np.int32)
+        v = t[:, 0] | (t[:, 1] << 8) | (t[:, 2] << 16)
+        v = np.where(v & 0x00800000, v | np.int32(-16777216), v).astype(np.int32)
+        return v.astype(np.float32) * np.float32(1.0 / 8388608.0)
+    raise ValueError(fmt)
+
+
+def float_to_pcm(x: np.ndarray, fmt: str) -> np.ndarray:
+    """alsa_common.cpp:87-127: clamp, scale in fp32, truncate toward zero."""
+    x = np.asarray(x, dtype=np.float32)
+    if fmt == "s16":
+        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999695), x))
+        return np.trunc(c * np.float32(32768.0)).astype("<i2").view(np.uint8)
+    if fmt == "s32":
+        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999999), x))
+        return np.trunc(c * np.float32(2147483648.0)).astype(np.int64).astype("<i4").view(np.uint8)
+    if fmt == "s24":
+        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999999), x))
+        v = np.trunc(c * np.float32(8388608.0)).astype(np.int32)
+        out = np.empty((v.size, 3), dtype=np.uint8)
+        out[:, 0] = v & 0xFF
+        out[:, 1] = (v >> 8) & 0xFF
+        out[:, 2] = (v >> 16) & 0xFF
+        return out.reshape(-1)
+    raise ValueError(fmt)
+
+
+# --------------------------------------------------------------------------
+# EQ: parser (eq_parser.cpp) and maths (eq_to_fir.cpp) -- numpy restatement,
+# pinned against oracle/_ref and tests/golden/eq_*.npz.
+# --------------------------------------------------------------------------
+FILTER_TYPES = [
+    "PK", "MODAL", "PEQ", "LP", "LPQ", "HP", "HPQ", "BP", "NO", "AP",
+    "LS", "HS", "LSC", "HSC", "LSQ", "HSQ", "LS 6dB", "LS 12dB", "HS 6dB", "HS 12dB",
+]
+_TYPE_ALIASES = {
+    "PK": 0, "PEAK": 0, "PEAKING": 0, "MODAL": 1, "PEQ": 2, "LP": 3, "LOWPASS": 3, "LPQ": 4,
+    "HP": 5, "HIGHPASS": 5, "HPQ": 6, "BP": 7, "BANDPASS": 7, "NO": 8, "NOTCH": 8, "AP": 9,
+    "ALLPASS": 9, "LS": 10, "LOWSHELF": 10, "HS": 11, "HIGHSHELF": 11, "LSC": 12, "HSC": 13,
+    "LSQ": 14, "HSQ": 15, "LS 6DB": 16, "LS6DB": 16, "LS 12DB": 17, "LS12DB": 17,
+    "HS 6DB": 18, "HS6DB": 18, "HS 12DB": 19, "HS12DB": 19,
+}
+
+
+def eq_parse_filter_type(s: str) -> int:
+    """eq_parser.cpp:71-141 (unknown -> PK)."""
+    return _TYPE_ALIASES.get(s.upper(), 0)
+
+
+_PREAMP = re.compile(r"Preamp:\s*([-+]?\d+\.?\d*)\s*[dD][bB]?", re.I)
+_FILTER = re.compile(r"Filter\s*(\d+)?\s*:\s*(ON|OFF)\s+(.+?)\s+Fc\s+([\d.]+)\s*(?:Hz)?", re.I)
+_GAIN = re.compile(r"Gain\s+([-+]?\d+\.?\d*)\s*dB", re.I)
+_Q = re.compile(r"Q\s+([\d.]+)", re.I)
+_BWOCT = re.compile(r"BW\s+Oct\s+([-+]?\d+\.?\d*)", re.I)
+_BW = re.compile(r"BW\s+([-+]?\d+\.?\d*)\s*(?:Hz)?", re.I)
+
+
+def eq_parse(text: str):
+    """eq_parser.cpp:177-259. Returns (ok, preamp_db, bands) with bands as dicts."""
+    preamp = 0.0
+    bands = []
+    for line in text.split("\n"):
+        line = line.strip(" \t\r\n")
+        if not line or line[0] in "#;":
+            continue
+        m = _PREAMP.search(line)
+        if m:
+            preamp = float(m.group(1))
+            continue
+        m = _FILTER.search(line)
+        if not m:
+            continue
+        band = dict(enabled=m.group(2).upper() == "ON", type=eq_parse_filter_type(m.group(3).strip(" \t\r\n")),
+                    frequency=float(m.group(4)), gain=0.0, q=1.0, has_bw_hz=False, bw_hz=0.0,
+                    has_bw_oct=False, bw_oct=0.0)
+        g = _GAIN.search(line)
+        if g:
+            band["gain"] = float(g.group(1))
+        q = _Q.search(line)
+        q_given = q is not None
+        if q:
+            band["q"] = float(q.group(1))
+        o = _BWOCT.search(line)
+        if o:
+            band["has_bw_oct"], band["bw_oct"] = True, float(o.group(1))
+            if not q_given:
+                bw = band["bw_oct"]
+                den = 2.0 * math.sinh(0.34657359037935203 * bw) if bw > 0 else 0.0
+                band["q"] = 1.0 / den if den > 0 else 1.0
+        b = _BW.search(line)
+        if b:
+            band["has_bw_hz"], band["bw_hz"] = True, float(b.group(1))
+            if not q_given and not band["has_bw_oct"]:
+                fc, bw = band["frequency"], band["bw_hz"]
+                band["q"] = fc / bw if (fc > 0 and bw > 0) else 1.0
+        bands.append(band)
+    return (bool(bands) or preamp != 0.0), preamp, bands
+
+
+def eq_biquad(band: dict, fs: float) -> np.ndarray:
+    """eq_to_fir.cpp:9-75: RBJ PK / LS / HS; everything else bypass."""
+    c = np.array([1.0, 0.0, 0.0, 0.0, 0.0])
+    if not band["enabled"] or band["gain"] == 0.0:
+        return c
+    pi = 3.14159265358979323846
+    A = 10.0 ** (band["gain"] / 40.0)
+    w0 = 2.0 * pi * band["frequency"] / fs
+    cw, sw = math.cos(w0), math.sin(w0)
+    alpha = sw / (2.0 * band["q"])
+    t = band["type"]
+    if t == 0:  # PK
+        b0, b1, b2 = 1.0 + alpha * A, -2.0 * cw, 1.0 - alpha * A
+        a0, a1, a2 = 1.0 + alpha / A, -2.0 * cw, 1.0 - alpha / A
+    elif t == 10:  # LS
+        s = 2.0 * math.sqrt(A) * alpha
+        b0 = A * ((A + 1.0) - (A - 1.0) * cw + s)
+        b1 = 2.0 * A * ((A - 1.0) - (A + 1.0) * cw)
+        b2 = A * ((A + 1.0) - (A - 1.0) * cw - s)
+        a0 = (A + 1.0) + (A - 1.0) * cw + s
+        a1 = -2.0 * ((A - 1.0) + (A + 1.0) * cw)
+        a2 = (A + 1.0) + (A - 1.0) * cw - s
+    elif t == 11:  # HS
+        s = 2.0 * math.sqrt(A) * alpha
+        b0 = A * ((A + 1.0) + (A - 1.0) * cw + s)
+        b1 = -2.0 * A * ((A - 1.0) + (A + 1.0) * cw)
+        b2 = A * ((A + 1.0) + (A - 1.0) * cw - s)
+        a0 = (A + 1.0) - (A - 1.0) * cw + s
+        a1 = 2.0 * ((A - 1.0) - (A + 1.0) * cw)
+        a2 = (A + 1.0) - (A - 1.0) * cw - s
+    else:
+        return c
+    return np.array([b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0])
+
+
+def eq_response(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    """computeEqResponseForFft (eq_to_fir.cpp:102-151): complex128 per bin."""
+    _, preamp, bands = eq_parse(text)
+    f = np.arange(num_bins, dtype=np.float64) * (fs_out / float(full_fft))
+    resp = np.ones(num_bins, dtype=np.complex128)
+    if preamp != 0.0:
+        resp *= 10.0 ** (preamp / 20.0)
+    w = 2.0 * 3.14159265358979323846 * np.abs(f) / fs_out
+    z = np.exp(-1j * w)
+    z2 = z * z
+    for b in bands:
+        if not b["enabled"]:
+            continue
+        c = eq_biquad(b, fs_out)
+        resp *= (c[0] + c[1] * z + c[2] * z2) / (1.0 + c[3] * z + c[4] * z2)
+    return resp
+
+
+def eq_magnitude(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    """computeEqMagnitudeForFft (eq_to_fir.cpp:153-177)."""
+    m = np.abs(eq_response(text, num_bins, full_fft, fs_out))
+    mx = m.max() if m.size else 0.0
+    return m / mx if mx > 1.0 else m
+
+
+def hermitian_extend(half: np.ndarray, n: int) -> np.ndarray:
+    """bins 0..n/2 -> full n-bin Hermitian spectrum (real impulse response)."""
+    full = np.empty(n, dtype=half.dtype)
+    full[: n // 2 + 1] = half
+    full[n // 2 + 1 :] = np.conj(half[1 : n // 2][::-1])
+    return full
+
+
+def eq_fused_stream_truth(x, h, factor, fft, block, nblocks, eq_half) -> np.ndarray:
+    """fp64 statement of THIS repo's EQ fusion (the reference has no call site,
+    SURVEY §8 hard part D -- parity of the fusion itself is UNPINNED): per block,
+    Y = FFT_N(timeBuffer) * FFT_N(h) * EQ  on all N bins (EQ Hermitian-extended,
+    Nyquist bin real part only), y = Re IFFT_N(Y), keep the last `block`."""
+    n = fft
+    ov = n - block
+    H = np.fft.fft(np.concatenate([np.asarray(h, np.float64), np.zeros(n - len(h))]))
+    half = np.array(eq_half, dtype=np.complex128).copy()
+    half[0] = half[0].real
+    half[n // 2] = half[n // 2].real
+    Ht = H * hermitian_extend(half, n)
+    x = np.asarray(x, np.float64)
+    nin = block // factor
+    overlap = np.zeros(ov)
+    out = np.empty((nblocks, block))
+    for b in range(nblocks):
+        t = np.zeros(n)
+        t[:ov] = overlap
+        t[ov::factor][:nin] = x[b * nin : (b + 1) * nin]
+        y = np.fft.ifft(np.fft.fft(t) * Ht).real
+        out[b] = y[ov:]
+        overlap = t[n - ov :].copy()
+    return out
