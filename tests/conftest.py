@@ -1,0 +1,67 @@
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def ups():
+    import totton_rasp_gpu_dsp_amd as m
+
+    return m
+
+
+@pytest.fixture(scope="session")
+def O():
+    import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def gpu(ups):
+    if ups.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need a GPU (there is no CPU fallback to test)")
+    return 0
+
+
+@pytest.fixture()
+def make_filter(tmp_path):
+    """Write taps + sidecar; returns the json path."""
+
+    def _make(taps, fft, block, factor=None, name="f", extra=None):
+        taps = np.asarray(taps, dtype="<f4")
+        taps.tofile(tmp_path / f"{name}.bin")
+        meta = dict(coefficients_bin=f"{name}.bin", taps=int(taps.size), fft_size=int(fft), block_size=int(block))
+        if factor is not None:
+            meta["upsample_factor"] = int(factor)
+        if extra:
+            meta.update(extra)
+        p = tmp_path / f"{name}.json"
+        p.write_text(json.dumps(meta))
+        return p
+
+    return _make
+
+
+def real_input(seed: int, n: int) -> np.ndarray:
+    """Same recipe as tests/golden/make_golden.py (seeded 0.2*N(0,1) float32)."""
+    return (np.random.default_rng(seed).standard_normal(n) * 0.2).astype(np.float32)
+
+
+def rel_err(a, b) -> float:
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,235 @@
+// TEST INFRASTRUCTURE ONLY -- CPU thread-emulation of the HIP kernels.
+//
+// Compiles the product's device headers (csrc/device/*.h) with
+// -DMIUPS_HOST_EMU, where blockIdx/threadIdx/__syncthreads/dynamic LDS are
+// provided by the shim below (one OS thread per GPU thread, one workgroup at a
+// time), and runs them under AddressSanitizer/UBSan on exact-size buffers.
+// Purpose: catch indexing and synchronisation mistakes on the CPU before a
+// kernel is launched on a GPU box (a faulting kernel can take the node down).
+// It is a separate executable under tests/; libmi_upsampler.so does not contain
+// it and has no code path to it.
+//
+// usage: emu_driver <filter.json> <flags> <streams> <channels> <in_fmt> <out_fmt>
+//                   <blocks_per_call> <calls> <in.bin> <out.bin> <fused|staged|auto>
+//   in.bin : [call][stream][frame][channel] samples of in_fmt
+//   out.bin: [call][stream][frame][channel] samples of out_fmt
+#include <pthread.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device/kernel_fused.h"
+#include "device/kernels_generic.h"
+#include "host/filter_config.h"
+#include "host/spectrum.h"
+
+namespace miups_emu {
+thread_local Dim3 t_threadIdx;
+thread_local Dim3 t_blockIdx;
+Dim3 g_blockDim;
+Dim3 g_gridDim;
+static pthread_barrier_t g_bar;
+static bool g_use_bar = false;
+static std::vector<char> g_shared;
+
+void barrier() {
+  if (g_use_bar) {
+    pthread_barrier_wait(&g_bar);
+  }
+}
+void *dyn_shared() { return g_shared.data(); }
+
+// run f() once per (block, thread); with barriers every thread of a block is a
+// real OS thread, otherwise threads run back to back.
+void launch(unsigned grid, unsigned block, size_t shmem, bool barriers, const std::function<void()> &f) {
+  g_gridDim.x = grid;
+  g_blockDim.x = block;
+  g_shared.assign(shmem, 0);
+  g_use_bar = barriers && block > 1;
+  for (unsigned b = 0; b < grid; ++b) {
+    if (!g_use_bar) {
+      for (unsigned t = 0; t < block; ++t) {
+        t_blockIdx.x = b;
+        t_threadIdx.x = t;
+        f();
+      }
+      continue;
+    }
+    pthread_barrier_init(&g_bar, nullptr, block);
+    std::vector<std::thread> threads;
+    threads.reserve(block);
+    for (unsigned t = 0; t < block; ++t) {
+      threads.emplace_back([&, b, t]() {
+        t_blockIdx.x = b;
+        t_threadIdx.x = t;
+        f();
+      });
+    }
+    for (auto &th : threads) {
+      th.join();
+    }
+    pthread_barrier_destroy(&g_bar);
+  }
+}
+}  // namespace miups_emu
+
+using namespace miups;
+
+namespace {
+
+unsigned Blocks(long long total, int threads) { return static_cast<unsigned>((total + threads - 1) / threads); }
+
+template <int DIR>
+void EmuPass(int R, const cf *in, cf *out, const cf *tw, int K, int Ns, int log2NsR, long long rows) {
+  const unsigned grid = Blocks(rows * (K / R), 64);
+  auto run = [&](auto kernel) { miups_emu::launch(grid, 64, 0, false, [&]() { kernel(in, out, tw, K, Ns, log2NsR, rows); }); };
+  switch (R) {
+    case 2: run(gen_pass_kernel<DIR, 2>); break;
+    case 4: run(gen_pass_kernel<DIR, 4>); break;
+    case 8: run(gen_pass_kernel<DIR, 8>); break;
+    default: run(gen_pass_kernel<DIR, 16>); break;
+  }
+}
+
+template <int DIR>
+cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
+  const int K = 1 << log2k;
+  int done = 0;
+  cf *src = a, *dst = b;
+  auto pass = [&](int log2r) {
+    EmuPass<DIR>(1 << log2r, src, dst, tw, K, 1 << done, done + log2r, rows);
+    done += log2r;
+    std::swap(src, dst);
+  };
+  if (log2k % 4) {
+    pass(log2k % 4);
+  }
+  while (done < log2k) {
+    pass(4);
+  }
+  return src;
+}
+
+template <int LOG2K>
+void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
+  using Cfg = FusedCfg<LOG2K>;
+  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() {
+    fused_kernel<LOG2K>(g, io, t.tw.data(), t.Wm.data(), t.Gs.data(), t.Gc.data());
+  });
+}
+
+bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
+  switch (g.log2k) {
+    case 5: EmuFused<5>(g, io, t, items); return true;
+    case 6: EmuFused<6>(g, io, t, items); return true;
+    case 7: EmuFused<7>(g, io, t, items); return true;
+    case 8: EmuFused<8>(g, io, t, items); return true;
+    case 9: EmuFused<9>(g, io, t, items); return true;
+    case 10: EmuFused<10>(g, io, t, items); return true;
+    case 11: EmuFused<11>(g, io, t, items); return true;
+    case 12: EmuFused<12>(g, io, t, items); return true;
+    case 13: EmuFused<13>(g, io, t, items); return true;
+    case 14: EmuFused<14>(g, io, t, items); return true;
+    default: return false;
+  }
+}
+
+std::vector<char> ReadAll(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc != 12) {
+    std::cerr << "bad usage\n";
+    return 2;
+  }
+  const std::string json = argv[1];
+  const int flags = std::atoi(argv[2]);
+  const int streams = std::atoi(argv[3]), channels = std::atoi(argv[4]);
+  const int inFmt = std::atoi(argv[5]), outFmt = std::atoi(argv[6]);
+  const int blocks = std::atoi(argv[7]), calls = std::atoi(argv[8]);
+  const std::string inPath = argv[9], outPath = argv[10], path = argv[11];
+
+  FilterConfig config;
+  std::vector<float> taps;
+  std::string error;
+  if (!ReadFilter(json, &config, &taps, &error)) {
+    std::cerr << error << "\n";
+    return 1;
+  }
+  FilterTables t;
+  if (!BuildTables(config, taps, nullptr, flags, &t, &error)) {
+    std::cerr << error << "\n";
+    return 1;
+  }
+  const Geometry g = t.geo;
+  const bool fusedOk = g.S == 1 && g.log2k >= 5 && g.log2k <= 14;
+  const bool fused = path == "fused" ? true : (path == "staged" ? false : fusedOk);
+  if (fused && !fusedOk) {
+    std::cerr << "fused path does not cover this geometry\n";
+    return 3;
+  }
+
+  const size_t inRow = static_cast<size_t>(blocks) * g.n_in * channels * pcm_bytes(inFmt);
+  const size_t outRow = static_cast<size_t>(blocks) * g.B * channels * pcm_bytes(outFmt);
+  const std::vector<char> all = ReadAll(inPath);
+  if (all.size() != inRow * streams * calls) {
+    std::cerr << "input size mismatch: " << all.size() << " vs " << inRow * streams * calls << "\n";
+    return 1;
+  }
+  const size_t histRow = static_cast<size_t>(g.hist_frames) * channels * pcm_bytes(inFmt);
+  std::vector<char> hist(histRow * streams, 0), hist2(histRow * streams, 0);
+  std::ofstream out(outPath, std::ios::binary | std::ios::trunc);
+
+  for (int call = 0; call < calls; ++call) {
+    // exact-size copies so ASan sees every out-of-range access
+    std::vector<char> in(all.begin() + call * inRow * streams, all.begin() + (call + 1) * inRow * streams);
+    std::vector<char> o(outRow * streams, 0);
+    IoDesc io{};
+    io.in = in.data();
+    io.hist = hist.data();
+    io.out = o.data();
+    io.in_stream_stride = static_cast<long long>(inRow);
+    io.hist_stream_stride = static_cast<long long>(histRow);
+    io.out_stream_stride = static_cast<long long>(outRow);
+    io.channels = channels;
+    io.streams = streams;
+    io.in_fmt = inFmt;
+    io.out_fmt = outFmt;
+    io.blocks = blocks;
+    const unsigned items = static_cast<unsigned>(blocks) * streams * channels;
+    if (fused) {
+      DispatchFused(g, io, t, items);
+    } else {
+      const size_t row = g.K;
+      std::vector<cf> w0(items * row), w1(items * row), w2(items * row * g.P), w3(items * row * g.P);
+      const long long elems = static_cast<long long>(items) * g.K;
+      miups_emu::launch(Blocks(elems, 64), 64, 0, false, [&]() { gen_load_kernel(g, io, w0.data(), 0, items); });
+      cf *Z = EmuFft<-1>(w0.data(), w1.data(), t.tw.data(), g.log2k, items);
+      miups_emu::launch(Blocks(elems, 64), 64, 0, false, [&]() {
+        gen_multiply_kernel(g, Z, w2.data(), t.Gs.data(), t.Gc.data(), t.Wm.data(), items);
+      });
+      cf *y = EmuFft<+1>(w2.data(), w3.data(), t.tw.data(), g.log2k, static_cast<long long>(items) * g.P);
+      miups_emu::launch(Blocks(elems * g.P, 64), 64, 0, false, [&]() { gen_store_kernel(g, io, y, 0, items); });
+    }
+    const long long histBytes = static_cast<long long>(histRow) * streams;
+    if (histBytes > 0) {
+      miups_emu::launch(Blocks(histBytes, 64), 64, 0, false, [&]() {
+        update_history_kernel(g, io, hist2.data(), static_cast<long long>(blocks) * g.n_in);
+      });
+      hist.swap(hist2);
+    }
+    out.write(o.data(), static_cast<std::streamsize>(o.size()));
+  }
+  return 0;
+}

@@ -1,0 +1,408 @@
+"""MI355X-native overlap-save FIR upsampler -- Python face of the C ABI.
+
+Thin ctypes bindings over ``lib/libmi_upsampler.so`` (``include/mi_upsampler.h``).
+The classes mirror the reference's operator interface for this path
+(``include/vulkan/vulkan_streaming_upsampler.h:12-49``): ``StreamingUpsampler``
+has ``load_filter / process_block / reset / config`` with the same argument
+meaning and the same failure behaviour (``load_filter`` -> ``(False, message)``,
+``process_block`` -> empty array). ``Filter`` + ``Engine`` are the batched form
+(all channels x many blocks per call, interleaved PCM resident in HBM).
+
+There is no CPU compute path in this package: if the shared library is missing
+the import fails, and every compute entry point fails loudly when no HIP device
+is usable. PyTorch is not required here; callers may pass raw device pointers
+(e.g. ``tensor.data_ptr()``) and a stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libmi_upsampler.so"
+
+PCM_F32, PCM_S16, PCM_S24_3LE, PCM_S32 = 0, 1, 2, 3
+PCM_NAMES = {"f32": PCM_F32, "s16": PCM_S16, "s24": PCM_S24_3LE, "s32": PCM_S32}
+PCM_BYTES = {PCM_F32: 4, PCM_S16: 2, PCM_S24_3LE: 3, PCM_S32: 4}
+LOAD_DEFAULT, LOAD_REF_COMPAT_SPECTRUM = 0, 1
+MI_OK, MI_ERR_ARG, MI_ERR_FILTER, MI_ERR_DEVICE, MI_ERR_SIZE = range(5)
+
+
+class UpsamplerError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("taps", C.c_size_t), ("fft_size", C.c_size_t), ("block_size", C.c_size_t),
+                ("upsample_factor", C.c_size_t), ("coefficients_path", C.c_char * 1024)]
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C totton-rasp-gpu-dsp_amd`). This package has no fallback implementation.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, cp, sz, i32, dbl = C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_double
+    f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    sig = {
+        "mi_ups_abi_version": (i32, []),
+        "mi_ups_device_count": (i32, []),
+        "mi_ups_last_error": (cp, []),
+        "mi_ups_create": (vp, [i32]),
+        "mi_ups_clone": (vp, [vp]),
+        "mi_ups_destroy": (None, [vp]),
+        "mi_ups_load_filter": (i32, [vp, cp, i32, cp, sz]),
+        "mi_ups_get_config": (i32, [vp, C.POINTER(_Config)]),
+        "mi_ups_process_block": (C.c_long, [vp, f32p, sz, f32p, sz]),
+        "mi_ups_reset": (i32, [vp]),
+        "mi_ups_set_eq": (i32, [vp, cp, dbl]),
+        "mi_filter_load": (i32, [i32, cp, i32, C.POINTER(vp), cp, sz]),
+        "mi_filter_from_taps": (i32, [i32, f32p, sz, sz, sz, sz, i32, C.POINTER(vp), cp, sz]),
+        "mi_filter_get_config": (i32, [vp, C.POINTER(_Config)]),
+        "mi_filter_set_eq": (i32, [vp, cp, dbl]),
+        "mi_eq_response_device": (i32, [i32, cp, sz, sz, dbl, f64p]),
+        "mi_filter_release": (None, [vp]),
+        "mi_engine_create": (i32, [vp, i32, i32, i32, i32, C.POINTER(vp)]),
+        "mi_engine_destroy": (None, [vp]),
+        "mi_engine_reset": (i32, [vp]),
+        "mi_engine_in_frames_per_block": (sz, [vp]),
+        "mi_engine_out_frames_per_block": (sz, [vp]),
+        "mi_engine_path": (cp, [vp]),
+        "mi_engine_process_device": (i32, [vp, vp, sz, vp, sz, sz, vp]),
+        "mi_engine_process_host": (i32, [vp, vp, sz, vp, sz, sz]),
+        "mi_engine_enable_kernel_timing": (i32, [vp, i32]),
+        "mi_engine_last_kernel_ms": (dbl, [vp]),
+        "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
+        "mi_read_filter": (i32, [cp, C.POINTER(_Config), cp, sz]),
+        "mi_resolve_filter_path": (i32, [cp, cp, cp, C.c_uint, C.c_uint, cp, sz, cp, sz]),
+        "mi_parse_format": (i32, [cp]),
+        "mi_bytes_per_sample": (sz, [i32]),
+        "mi_pcm_to_float": (i32, [vp, i32, sz, f32p]),
+        "mi_float_to_pcm": (i32, [f32p, sz, i32, vp]),
+        "mi_eq_parse": (C.c_long, [cp, f64p, f64p, sz]),
+        "mi_eq_parse_filter_type": (i32, [cp]),
+        "mi_eq_filter_type_name": (cp, [i32]),
+        "mi_eq_biquad": (i32, [i32, i32, dbl, dbl, dbl, dbl, f64p]),
+        "mi_eq_response_host": (i32, [cp, sz, sz, dbl, f64p]),
+        "mi_eq_magnitude_host": (i32, [cp, sz, sz, dbl, f64p]),
+        "mi_tables_build": (i32, [cp, i32, cp, dbl, C.POINTER(vp), cp, sz]),
+        "mi_tables_geometry": (i32, [vp, C.POINTER(i32)]),
+        "mi_tables_size": (sz, [vp, i32]),
+        "mi_tables_copy": (i32, [vp, i32, f32p, sz]),
+        "mi_tables_free": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+EXPORTED_SYMBOLS = [
+    "mi_ups_abi_version", "mi_ups_device_count", "mi_ups_last_error", "mi_ups_create", "mi_ups_clone",
+    "mi_ups_destroy", "mi_ups_load_filter", "mi_ups_get_config", "mi_ups_process_block", "mi_ups_reset",
+    "mi_ups_set_eq", "mi_filter_load", "mi_filter_from_taps", "mi_filter_get_config", "mi_filter_set_eq",
+    "mi_eq_response_device", "mi_filter_release", "mi_engine_create", "mi_engine_destroy", "mi_engine_reset",
+    "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
+    "mi_engine_process_host", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
+    "mi_engine_kernel_ms_stats", "mi_read_filter",
+    "mi_resolve_filter_path", "mi_parse_format", "mi_bytes_per_sample", "mi_pcm_to_float", "mi_float_to_pcm",
+    "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
+    "mi_eq_magnitude_host", "mi_tables_build", "mi_tables_geometry", "mi_tables_size", "mi_tables_copy",
+    "mi_tables_free",
+]
+
+
+def last_error() -> str:
+    return lib.mi_ups_last_error().decode(errors="replace")
+
+
+def device_count() -> int:
+    return int(lib.mi_ups_device_count())
+
+
+def _cfg(c: _Config) -> dict:
+    return dict(taps=int(c.taps), fft_size=int(c.fft_size), block_size=int(c.block_size),
+                upsample_factor=int(c.upsample_factor), coefficients_path=c.coefficients_path.decode())
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped single-channel operator
+# ---------------------------------------------------------------------------
+class StreamingUpsampler:
+    """One channel, host float buffers: LoadFilter / ProcessBlock / Reset /
+    GetConfig of the reference class, backed by HIP."""
+
+    def __init__(self, device: int = 0, _handle=None):
+        self.device = device
+        self._h = _handle if _handle is not None else lib.mi_ups_create(device)
+        if not self._h:
+            raise UpsamplerError("mi_ups_create failed")
+
+    def load_filter(self, json_path, flags: int = LOAD_DEFAULT) -> tuple[bool, str]:
+        err = C.create_string_buffer(1280)
+        rc = lib.mi_ups_load_filter(self._h, os.fsencode(str(json_path)), flags, err, len(err))
+        return rc == MI_OK, err.value.decode(errors="replace")
+
+    @property
+    def config(self) -> dict:
+        c = _Config()
+        lib.mi_ups_get_config(self._h, C.byref(c))
+        return _cfg(c)
+
+    def process_block(self, x, count: int | None = None) -> np.ndarray:
+        """Returns block_size float32 samples, or an EMPTY array in every case
+        where the reference returns an empty vector."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        cap = max(self.config["block_size"], 1)
+        out = np.empty(cap, dtype=np.float32)
+        n = lib.mi_ups_process_block(self._h, _f32(x) if x.size else None, x.size if count is None else count,
+                                     _f32(out), cap)
+        return out[: max(int(n), 0)].copy()
+
+    def reset(self) -> None:
+        if lib.mi_ups_reset(self._h) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def set_eq(self, apo_text: str, fs_out: float) -> None:
+        if lib.mi_ups_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def clone(self) -> "StreamingUpsampler":
+        h = lib.mi_ups_clone(self._h)
+        if not h:
+            raise UpsamplerError(last_error())
+        return StreamingUpsampler(self.device, _handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi_ups_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+# ---------------------------------------------------------------------------
+# batched engine
+# ---------------------------------------------------------------------------
+class Filter:
+    def __init__(self, json_path=None, device: int = 0, flags: int = LOAD_DEFAULT, *, taps=None, fft_size=None,
+                 block_size=None, upsample_factor=1):
+        self.device = device
+        h = C.c_void_p()
+        err = C.create_string_buffer(1280)
+        if json_path is not None:
+            rc = lib.mi_filter_load(device, os.fsencode(str(json_path)), flags, C.byref(h), err, len(err))
+        else:
+            t = np.ascontiguousarray(taps, dtype=np.float32)
+            rc = lib.mi_filter_from_taps(device, _f32(t), t.size, fft_size, block_size, upsample_factor, flags,
+                                         C.byref(h), err, len(err))
+        if rc != MI_OK:
+            raise UpsamplerError(err.value.decode(errors="replace") or last_error())
+        self._h = h
+
+    @property
+    def config(self) -> dict:
+        c = _Config()
+        lib.mi_filter_get_config(self._h, C.byref(c))
+        return _cfg(c)
+
+    def set_eq(self, apo_text: str, fs_out: float) -> None:
+        if lib.mi_filter_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi_filter_release(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Engine:
+    """`streams` independent streams x `channels` interleaved channels."""
+
+    def __init__(self, filt: Filter, streams: int = 1, channels: int = 2, in_fmt: int = PCM_S32,
+                 out_fmt: int = PCM_S32):
+        self.filter = filt
+        self.streams, self.channels, self.in_fmt, self.out_fmt = streams, channels, in_fmt, out_fmt
+        h = C.c_void_p()
+        if lib.mi_engine_create(filt._h, streams, channels, in_fmt, out_fmt, C.byref(h)) != MI_OK:
+            raise UpsamplerError(last_error())
+        self._h = h
+        self.in_frames = int(lib.mi_engine_in_frames_per_block(h))
+        self.out_frames = int(lib.mi_engine_out_frames_per_block(h))
+        self.path = lib.mi_engine_path(h).decode()
+
+    def in_bytes(self, blocks: int) -> int:
+        return blocks * self.in_frames * self.channels * PCM_BYTES[self.in_fmt]
+
+    def out_bytes(self, blocks: int) -> int:
+        return blocks * self.out_frames * self.channels * PCM_BYTES[self.out_fmt]
+
+    def process_device(self, d_in: int, d_out: int, blocks: int, stream: int = 0, in_stride: int | None = None,
+                       out_stride: int | None = None) -> None:
+        """Enqueue only. d_in/d_out are device addresses (e.g. tensor.data_ptr())."""
+        rc = lib.mi_engine_process_device(self._h, C.c_void_p(d_in), self.in_bytes(blocks) if in_stride is None else in_stride,
+                                          C.c_void_p(d_out), self.out_bytes(blocks) if out_stride is None else out_stride,
+                                          blocks, C.c_void_p(stream))
+        if rc != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def process_host(self, x: np.ndarray, blocks: int) -> np.ndarray:
+        """x: raw bytes / array laid out [stream][frame][channel]; returns uint8 bytes same layout."""
+        raw = np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+        if raw.size != self.in_bytes(blocks) * self.streams:
+            raise UpsamplerError(f"input holds {raw.size} bytes, expected {self.in_bytes(blocks) * self.streams}")
+        out = np.empty(self.out_bytes(blocks) * self.streams, dtype=np.uint8)
+        rc = lib.mi_engine_process_host(self._h, raw.ctypes.data_as(C.c_void_p), self.in_bytes(blocks),
+                                        out.ctypes.data_as(C.c_void_p), self.out_bytes(blocks), blocks)
+        if rc != MI_OK:
+            raise UpsamplerError(last_error())
+        return out
+
+    def reset(self) -> None:
+        if lib.mi_engine_reset(self._h) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def enable_kernel_timing(self, slots: int = 1) -> None:
+        if lib.mi_engine_enable_kernel_timing(self._h, int(slots)) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def kernel_ms_stats(self) -> dict:
+        a, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        if lib.mi_engine_kernel_ms_stats(self._h, C.byref(a), C.byref(lo), C.byref(hi), C.byref(n)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return dict(avg=a.value, min=lo.value, max=hi.value, count=n.value)
+
+    def last_kernel_ms(self) -> float:
+        return float(lib.mi_engine_last_kernel_ms(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+# ---------------------------------------------------------------------------
+# host-side helpers (no GPU)
+# ---------------------------------------------------------------------------
+def read_filter(json_path) -> tuple[bool, str, dict | None]:
+    c = _Config()
+    err = C.create_string_buffer(1280)
+    rc = lib.mi_read_filter(os.fsencode(str(json_path)), C.byref(c), err, len(err))
+    return rc == MI_OK, err.value.decode(errors="replace"), (_cfg(c) if rc == MI_OK else None)
+
+
+def resolve_filter_path(filter_path: str, filter_dir: str, phase: str, ratio: int, input_rate: int):
+    out = C.create_string_buffer(4096)
+    err = C.create_string_buffer(1280)
+    ok = lib.mi_resolve_filter_path(os.fsencode(filter_path), os.fsencode(filter_dir), phase.encode(), ratio,
+                                    input_rate, out, len(out), err, len(err))
+    return (os.fsdecode(out.value) if ok else None), err.value.decode(errors="replace")
+
+
+def parse_format(name: str) -> int:
+    return int(lib.mi_parse_format(name.encode()))
+
+
+def bytes_per_sample(fmt: int) -> int:
+    return int(lib.mi_bytes_per_sample(fmt))
+
+
+def pcm_to_float(raw, fmt: int) -> np.ndarray:
+    b = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8))
+    n = b.size // PCM_BYTES[fmt]
+    out = np.empty(n, dtype=np.float32)
+    if lib.mi_pcm_to_float(b.ctypes.data_as(C.c_void_p), fmt, n, _f32(out)) != MI_OK:
+        raise UpsamplerError("mi_pcm_to_float")
+    return out
+
+
+def float_to_pcm(x, fmt: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.size * PCM_BYTES[fmt], dtype=np.uint8)
+    if lib.mi_float_to_pcm(_f32(x), x.size, fmt, out.ctypes.data_as(C.c_void_p)) != MI_OK:
+        raise UpsamplerError("mi_float_to_pcm")
+    return out
+
+
+def eq_parse(text: str):
+    bands = np.zeros(9 * 256)
+    pre = C.c_double()
+    n = lib.mi_eq_parse(text.encode(), C.byref(pre), _f64(bands), 256)
+    if n < 0:
+        return None
+    return pre.value, bands[: 9 * n].reshape(n, 9).copy()
+
+
+def eq_parse_filter_type(s: str) -> int:
+    return int(lib.mi_eq_parse_filter_type(s.encode()))
+
+
+def eq_filter_type_name(t: int) -> str:
+    return lib.mi_eq_filter_type_name(t).decode()
+
+
+def eq_biquad(enabled, type_id, freq, gain, q, fs) -> np.ndarray:
+    out = np.empty(5)
+    lib.mi_eq_biquad(int(enabled), int(type_id), freq, gain, q, fs, _f64(out))
+    return out
+
+
+def eq_response_host(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    out = np.empty(num_bins, dtype=np.complex128)
+    lib.mi_eq_response_host(text.encode(), num_bins, full_fft, fs_out, _f64(out.view(np.float64)))
+    return out
+
+
+def eq_magnitude_host(text: str, num_bins: int, full_fft: int, fs_out: float) -> np.ndarray:
+    out = np.empty(num_bins)
+    lib.mi_eq_magnitude_host(text.encode(), num_bins, full_fft, fs_out, _f64(out))
+    return out
+
+
+def eq_response_device(text: str, num_bins: int, full_fft: int, fs_out: float, device: int = 0) -> np.ndarray:
+    out = np.empty(num_bins, dtype=np.complex128)
+    if lib.mi_eq_response_device(device, text.encode(), num_bins, full_fft, fs_out, _f64(out.view(np.float64))) != MI_OK:
+        raise UpsamplerError(last_error())
+    return out
+
+
+def build_tables(json_path, flags: int = LOAD_DEFAULT, apo_text: str | None = None, fs_out: float = 0.0) -> dict:
+    """Host-built kernel tables (for inspection/tests)."""
+    h = C.c_void_p()
+    err = C.create_string_buffer(1280)
+    rc = lib.mi_tables_build(os.fsencode(str(json_path)), flags, apo_text.encode() if apo_text else None, fs_out,
+                             C.byref(h), err, len(err))
+    if rc != MI_OK:
+        raise UpsamplerError(err.value.decode(errors="replace"))
+    try:
+        g = (C.c_int * 10)()
+        lib.mi_tables_geometry(h, g)
+        names = ["log2k", "K", "M", "P", "S", "Oc", "Bc", "n_in", "B", "hist_frames"]
+        res = {"geometry": dict(zip(names, [int(v) for v in g]))}
+        for which, name in enumerate(["Gs", "Gc", "Wm", "tw"]):
+            n = int(lib.mi_tables_size(h, which))
+            a = np.empty(n, dtype=np.complex64)
+            lib.mi_tables_copy(h, which, _f32(a.view(np.float32)), n)
+            res[name] = a
+        return res
+    finally:
+        lib.mi_tables_free(h)

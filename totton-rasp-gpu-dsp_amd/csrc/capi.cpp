@@ -1,0 +1,431 @@
+// extern "C" boundary (include/mi_upsampler.h). No exceptions escape; every
+// failure leaves a message in the thread-local last-error slot.
+#include "../../include/mi_upsampler.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using miups::DeviceFilter;
+using miups::Engine;
+using miups::FilterConfig;
+
+struct mi_filter {
+  std::shared_ptr<DeviceFilter> filter;
+};
+
+struct mi_engine {
+  std::unique_ptr<Engine> engine;
+};
+
+struct mi_ups {
+  int device = 0;
+  bool initialized = false;
+  FilterConfig config{};
+  std::shared_ptr<DeviceFilter> filter;
+  std::unique_ptr<Engine> engine;
+  bool privateFilter = false;  // true once this handle forked its own tables (EQ)
+};
+
+namespace {
+
+void CopyMessage(const std::string &m, char *dst, size_t cap) {
+  if (dst && cap) {
+    std::strncpy(dst, m.c_str(), cap - 1);
+    dst[cap - 1] = '\0';
+  }
+}
+
+int Fail(int code, const std::string &m, char *err = nullptr, size_t cap = 0) {
+  miups::SetLastError(m);
+  CopyMessage(m, err, cap);
+  return code;
+}
+
+void FillConfig(const FilterConfig &c, mi_ups_config *out) {
+  out->taps = c.taps;
+  out->fft_size = c.fftSize;
+  out->block_size = c.blockSize;
+  out->upsample_factor = c.upsampleFactor;
+  CopyMessage(c.coefficientsPath, out->coefficients_path, sizeof(out->coefficients_path));
+}
+
+template <typename F>
+auto Guard(F &&f, decltype(f()) onThrow) -> decltype(f()) {
+  try {
+    return f();
+  } catch (const std::exception &e) {
+    miups::SetLastError(std::string("internal error: ") + e.what());
+  } catch (...) {
+    miups::SetLastError("internal error");
+  }
+  return onThrow;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_ups_abi_version(void) { return MI_UPS_ABI_VERSION; }
+
+int mi_ups_device_count(void) { return miups::DeviceCount(); }
+
+const char *mi_ups_last_error(void) { return miups::LastError().c_str(); }
+
+// ---------------------------------------------------------------- level 1 --
+mi_ups *mi_ups_create(int device) {
+  return Guard(
+      [&]() -> mi_ups * {
+        mi_ups *h = new (std::nothrow) mi_ups();
+        if (h) {
+          h->device = device;
+        }
+        return h;
+      },
+      nullptr);
+}
+
+void mi_ups_destroy(mi_ups *h) { delete h; }
+
+mi_ups *mi_ups_clone(const mi_ups *other) {
+  return Guard(
+      [&]() -> mi_ups * {
+        if (!other) {
+          Fail(MI_ERR_ARG, "null handle");
+          return nullptr;
+        }
+        std::unique_ptr<mi_ups> h(new mi_ups());
+        h->device = other->device;
+        h->initialized = other->initialized;
+        h->config = other->config;
+        h->filter = other->filter;  // tables are immutable while shared
+        if (other->engine) {
+          std::string error;
+          h->engine = other->engine->Clone(&error);
+          if (!h->engine) {
+            Fail(MI_ERR_DEVICE, error);
+            return nullptr;
+          }
+        }
+        return h.release();
+      },
+      nullptr);
+}
+
+int mi_ups_load_filter(mi_ups *h, const char *json_path, int flags, char *err, size_t errcap) {
+  return Guard(
+      [&]() -> int {
+        if (!h || !json_path) {
+          return Fail(MI_ERR_ARG, "null argument", err, errcap);
+        }
+        FilterConfig config;
+        std::vector<float> taps;
+        std::string error;
+        if (!miups::ReadFilter(json_path, &config, &taps, &error)) {
+          return Fail(MI_ERR_FILTER, error, err, errcap);
+        }
+        auto filter = DeviceFilter::Create(h->device, config, std::move(taps), flags, &error);
+        if (!filter) {
+          return Fail(MI_ERR_DEVICE, error, err, errcap);
+        }
+        auto engine = Engine::Create(filter, 1, 1, MI_PCM_F32, MI_PCM_F32, &error);
+        if (!engine) {
+          return Fail(MI_ERR_DEVICE, error, err, errcap);
+        }
+        h->config = config;
+        h->filter = std::move(filter);
+        h->engine = std::move(engine);
+        h->privateFilter = true;
+        h->initialized = true;
+        CopyMessage("", err, errcap);
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_ups_get_config(const mi_ups *h, mi_ups_config *out) {
+  if (!h || !out) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  FillConfig(h->config, out);
+  return MI_OK;
+}
+
+long mi_ups_process_block(mi_ups *h, const float *input, size_t count, float *out, size_t outcap) {
+  return Guard(
+      [&]() -> long {
+        // the reference's guards, in its order (vulkan_streaming_upsampler.cpp:502-526)
+        if (!h || !h->initialized || !input) {
+          Fail(MI_ERR_ARG, "not initialised or null input");
+          return 0;
+        }
+        if (count == 0) {
+          Fail(MI_ERR_SIZE, "count == 0");
+          return 0;
+        }
+        const size_t factor = h->config.upsampleFactor > 1 ? h->config.upsampleFactor : 1;
+        if (h->config.blockSize % factor != 0) {
+          Fail(MI_ERR_SIZE, "block_size not divisible by upsample_factor");
+          return 0;
+        }
+        const size_t expect = h->config.blockSize / factor;
+        if (expect == 0 || count != expect) {
+          Fail(MI_ERR_SIZE, "count must equal block_size / upsample_factor");
+          return 0;
+        }
+        if (!out || outcap < h->config.blockSize) {
+          Fail(MI_ERR_SIZE, "output buffer too small");
+          return 0;
+        }
+        std::string error;
+        if (!h->engine->ProcessHost(input, 0, out, 0, 1, &error)) {
+          Fail(MI_ERR_DEVICE, error);
+          return 0;
+        }
+        return static_cast<long>(h->config.blockSize);
+      },
+      0L);
+}
+
+int mi_ups_reset(mi_ups *h) {
+  return Guard(
+      [&]() -> int {
+        if (!h) {
+          return Fail(MI_ERR_ARG, "null handle");
+        }
+        if (!h->engine) {
+          return MI_OK;  // Reset() on an unloaded instance is a no-op in the reference too
+        }
+        std::string error;
+        return h->engine->Reset(&error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_ups_set_eq(mi_ups *h, const char *apo_text, double fs_out) {
+  return Guard(
+      [&]() -> int {
+        if (!h || !h->initialized) {
+          return Fail(MI_ERR_ARG, "not initialised");
+        }
+        std::string error;
+        if (h->filter.use_count() > 1) {
+          // clones share tables; an EQ change must stay private to this handle
+          auto own = h->filter->Fork(&error);
+          if (!own) {
+            return Fail(MI_ERR_DEVICE, error);
+          }
+          h->filter = own;
+          h->engine->Rebind(h->filter);
+        }
+        if (!h->filter->SetEq(apo_text ? apo_text : "", fs_out, &error)) {
+          return Fail(MI_ERR_DEVICE, error);
+        }
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+// ---------------------------------------------------------------- level 2 --
+int mi_filter_load(int device, const char *json_path, int flags, mi_filter **out, char *err, size_t errcap) {
+  return Guard(
+      [&]() -> int {
+        if (!json_path || !out) {
+          return Fail(MI_ERR_ARG, "null argument", err, errcap);
+        }
+        FilterConfig config;
+        std::vector<float> taps;
+        std::string error;
+        if (!miups::ReadFilter(json_path, &config, &taps, &error)) {
+          return Fail(MI_ERR_FILTER, error, err, errcap);
+        }
+        auto filter = DeviceFilter::Create(device, config, std::move(taps), flags, &error);
+        if (!filter) {
+          return Fail(MI_ERR_DEVICE, error, err, errcap);
+        }
+        *out = new mi_filter{std::move(filter)};
+        CopyMessage("", err, errcap);
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_filter_from_taps(int device, const float *taps, size_t n_taps, size_t fft_size, size_t block_size,
+                        size_t upsample_factor, int flags, mi_filter **out, char *err, size_t errcap) {
+  return Guard(
+      [&]() -> int {
+        if (!taps || !out) {
+          return Fail(MI_ERR_ARG, "null argument", err, errcap);
+        }
+        // same rules, same messages as the sidecar loader
+        if (n_taps == 0 || fft_size == 0 || block_size == 0) {
+          return Fail(MI_ERR_FILTER, "taps/fft_size/block_size must be set and non-zero", err, errcap);
+        }
+        if ((fft_size & (fft_size - 1)) != 0) {
+          return Fail(MI_ERR_FILTER, "fft_size must be power of two", err, errcap);
+        }
+        if (block_size >= fft_size) {
+          return Fail(MI_ERR_FILTER, "block_size must be smaller than fft_size", err, errcap);
+        }
+        if (fft_size - block_size != n_taps - 1) {
+          return Fail(MI_ERR_FILTER, "block_size must satisfy fft_size - block_size == taps - 1", err, errcap);
+        }
+        FilterConfig config;
+        config.taps = n_taps;
+        config.fftSize = fft_size;
+        config.blockSize = block_size;
+        config.upsampleFactor = upsample_factor == 0 ? 1 : upsample_factor;
+        if (config.upsampleFactor > 1 && block_size % config.upsampleFactor != 0) {
+          return Fail(MI_ERR_FILTER, "block_size must be divisible by upsample_factor", err, errcap);
+        }
+        std::string error;
+        auto filter =
+            DeviceFilter::Create(device, config, std::vector<float>(taps, taps + n_taps), flags, &error);
+        if (!filter) {
+          return Fail(MI_ERR_DEVICE, error, err, errcap);
+        }
+        *out = new mi_filter{std::move(filter)};
+        CopyMessage("", err, errcap);
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_filter_get_config(const mi_filter *f, mi_ups_config *out) {
+  if (!f || !out) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  FillConfig(f->filter->config(), out);
+  return MI_OK;
+}
+
+int mi_filter_set_eq(mi_filter *f, const char *apo_text, double fs_out) {
+  return Guard(
+      [&]() -> int {
+        if (!f) {
+          return Fail(MI_ERR_ARG, "null filter");
+        }
+        std::string error;
+        return f->filter->SetEq(apo_text ? apo_text : "", fs_out, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_eq_response_device(int device, const char *apo_text, size_t num_bins, size_t full_fft, double fs_out,
+                          double *out_reim) {
+  return Guard(
+      [&]() -> int {
+        if (!apo_text || !out_reim) {
+          return Fail(MI_ERR_ARG, "null argument");
+        }
+        std::vector<std::complex<double>> r;
+        std::string error;
+        if (!miups::EqResponseDevice(device, apo_text, num_bins, full_fft, fs_out, &r, &error)) {
+          return Fail(MI_ERR_DEVICE, error);
+        }
+        std::memcpy(out_reim, r.data(), r.size() * sizeof(std::complex<double>));
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+void mi_filter_release(mi_filter *f) { delete f; }
+
+int mi_engine_create(mi_filter *f, int streams, int channels, int in_fmt, int out_fmt, mi_engine **out) {
+  return Guard(
+      [&]() -> int {
+        if (!f || !out) {
+          return Fail(MI_ERR_ARG, "null argument");
+        }
+        std::string error;
+        auto e = Engine::Create(f->filter, streams, channels, in_fmt, out_fmt, &error);
+        if (!e) {
+          return Fail(MI_ERR_DEVICE, error);
+        }
+        *out = new mi_engine{std::move(e)};
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+void mi_engine_destroy(mi_engine *e) { delete e; }
+
+int mi_engine_reset(mi_engine *e) {
+  return Guard(
+      [&]() -> int {
+        if (!e) {
+          return Fail(MI_ERR_ARG, "null engine");
+        }
+        std::string error;
+        return e->engine->Reset(&error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+size_t mi_engine_in_frames_per_block(const mi_engine *e) {
+  return e ? static_cast<size_t>(e->engine->filter()->geometry().n_in) : 0;
+}
+
+size_t mi_engine_out_frames_per_block(const mi_engine *e) {
+  return e ? static_cast<size_t>(e->engine->filter()->geometry().B) : 0;
+}
+
+const char *mi_engine_path(const mi_engine *e) { return (e && e->engine->fused()) ? "fused" : "staged"; }
+
+int mi_engine_process_device(mi_engine *e, const void *d_in, size_t in_stream_stride_bytes, void *d_out,
+                             size_t out_stream_stride_bytes, size_t blocks, void *hip_stream) {
+  return Guard(
+      [&]() -> int {
+        if (!e) {
+          return Fail(MI_ERR_ARG, "null engine");
+        }
+        std::string error;
+        return e->engine->ProcessDevice(d_in, in_stream_stride_bytes, d_out, out_stream_stride_bytes, blocks,
+                                        hip_stream, &error)
+                   ? MI_OK
+                   : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_engine_process_host(mi_engine *e, const void *h_in, size_t in_stream_stride_bytes, void *h_out,
+                           size_t out_stream_stride_bytes, size_t blocks) {
+  return Guard(
+      [&]() -> int {
+        if (!e) {
+          return Fail(MI_ERR_ARG, "null engine");
+        }
+        std::string error;
+        return e->engine->ProcessHost(h_in, in_stream_stride_bytes, h_out, out_stream_stride_bytes, blocks, &error)
+                   ? MI_OK
+                   : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_engine_enable_kernel_timing(mi_engine *e, int slots) {
+  return Guard(
+      [&]() -> int {
+        if (!e || slots < 0 || slots > 65536) {
+          return Fail(MI_ERR_ARG, "bad timing slot count");
+        }
+        std::string error;
+        return e->engine->EnableTiming(slots, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double *max_ms, int *count) {
+  if (!e || !avg || !min_ms || !max_ms || !count) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  return e->engine->KernelMsStats(avg, min_ms, max_ms, count) ? MI_OK : Fail(MI_ERR_DEVICE, "no timed calls recorded");
+}
+
+double mi_engine_last_kernel_ms(mi_engine *e) { return e ? e->engine->LastKernelMs() : -1.0; }
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Device-side common definitions for the MI355X (gfx950) upsampler kernels.
+//
+// The kernels are written against a tiny macro layer so that the SAME source
+// can also be compiled by g++ into a thread-emulated debug build that lives
+// under tests/ (tests/emu): that build exists only to bounds-check and
+// cross-check kernel indexing on the CPU before a kernel is ever launched on a
+// GPU box. It is never part of libmi_upsampler.so and no product entry point
+// can reach it -- the product path is HIP only and fails loudly without a GPU.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#if defined(MIUPS_HOST_EMU)
+#include <cmath>
+namespace miups_emu {
+struct Dim3 {
+  unsigned x = 1, y = 1, z = 1;
+};
+extern thread_local Dim3 t_threadIdx;
+extern thread_local Dim3 t_blockIdx;
+extern Dim3 g_blockDim;
+extern Dim3 g_gridDim;
+void barrier();
+void *dyn_shared();
+}  // namespace miups_emu
+#define MI_DEVICE inline
+#define MI_HD inline
+#define MI_GLOBAL static
+#define MI_SYNC() ::miups_emu::barrier()
+#define MI_TID_X (::miups_emu::t_threadIdx.x)
+#define MI_BID_X (::miups_emu::t_blockIdx.x)
+#define MI_BID_Y (::miups_emu::t_blockIdx.y)
+#define MI_BDIM_X (::miups_emu::g_blockDim.x)
+#define MI_GDIM_X (::miups_emu::g_gridDim.x)
+#define MI_DYN_SHARED(type, name) type *name = static_cast<type *>(::miups_emu::dyn_shared())
+#define MI_UNROLL
+#define MI_LAUNCH_BOUNDS(t, w)
+#define MI_RESTRICT __restrict__
+#else
+#include <hip/hip_runtime.h>
+#define MI_DEVICE __device__ __forceinline__
+#define MI_HD __host__ __device__ inline
+#define MI_GLOBAL __global__
+#define MI_SYNC() __syncthreads()
+#define MI_TID_X (threadIdx.x)
+#define MI_BID_X (blockIdx.x)
+#define MI_BID_Y (blockIdx.y)
+#define MI_BDIM_X (blockDim.x)
+#define MI_GDIM_X (gridDim.x)
+#define MI_DYN_SHARED(type, name)                                  \
+  extern __shared__ __attribute__((aligned(16))) char mi_dyn_smem_[]; \
+  type *name = reinterpret_cast<type *>(mi_dyn_smem_)
+#define MI_UNROLL _Pragma("unroll")
+#define MI_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
+#define MI_RESTRICT __restrict__
+#endif
+
+namespace miups {
+
+// complex float, 8 bytes, layout-compatible with float2 / std::complex<float>
+struct alignas(8) cf {
+  float x, y;
+};
+
+MI_DEVICE cf mk(float x, float y) {
+  cf r;
+  r.x = x;
+  r.y = y;
+  return r;
+}
+MI_DEVICE cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+MI_DEVICE cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+MI_DEVICE cf cmul(cf a, cf b) {
+  return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+MI_DEVICE cf cmulc(cf a, cf b) {
+  return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+MI_DEVICE cf cconj(cf a) { return mk(a.x, -a.y); }
+MI_DEVICE cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+// j*a and -j*a
+MI_DEVICE cf cmulj(cf a) { return mk(-a.y, a.x); }
+MI_DEVICE cf cmulnj(cf a) { return mk(a.y, -a.x); }
+
+// PCM sample formats at the batched boundary. Values mirror include/mi_upsampler.h.
+enum PcmFormat : int { kF32 = 0, kS16 = 1, kS24_3LE = 2, kS32 = 3 };
+
+MI_HD int pcm_bytes(int fmt) {
+  return fmt == kS16 ? 2 : (fmt == kS24_3LE ? 3 : 4);
+}
+
+// Geometry shared by every kernel of one loaded filter. All sizes in samples
+// of the compact (per-phase) domain unless stated.
+//   N = fft_size, B = block_size, O = N - B, Lf = upsample_factor
+//   P = number of output phases handled in the frequency domain (P = Lf when
+//       N % Lf == 0, else 1), S = Lf / P = zero-stuff stride left in the
+//       time domain (1 whenever P = Lf)
+//   M = N / P real samples per channel-block, K = M / 2 complex points
+//   Oc = O / P history samples, Bc = B / P new compact samples per block
+struct Geometry {
+  int log2k;      // K = 1 << log2k
+  int K;          // complex FFT length
+  int M;          // 2K
+  int P;          // phases
+  int S;          // residual stuffing stride
+  int Oc;         // compact history length
+  int Bc;         // compact new samples per block ( = n_in * S )
+  int n_in;       // input frames per block (B / Lf)
+  int B;          // output frames per block
+  int hist_frames;  // frames of input history kept per stream = ceil(Oc / S)
+};
+
+// Where samples live for one batched call. Frames are interleaved:
+// sample(stream s, frame f, channel c) at
+//   base + s * stream_stride_bytes + (f * channels + c) * bytes(fmt)
+struct IoDesc {
+  const void *in;        // new input frames of this call (device)
+  const void *hist;      // last hist_frames frames before this call (device)
+  void *out;             // output frames (device)
+  long long in_stream_stride;    // bytes
+  long long hist_stream_stride;  // bytes
+  long long out_stream_stride;   // bytes
+  int channels;          // channels per stream
+  int streams;
+  int in_fmt;
+  int out_fmt;
+  int blocks;            // blocks processed by this call
+};
+
+}  // namespace miups

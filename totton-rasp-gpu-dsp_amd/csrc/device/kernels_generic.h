@@ -1,0 +1,186 @@
+// Any-size path: the same algorithm as the fused kernel (kernel_fused.h) cut
+// into one launch per stage with the work arrays in HBM. Used when the
+// per-channel-block transform does not fit one CU's LDS (K > 16384, e.g. the
+// 2x filters at N = 131072 and the "2m" filters) and for degenerate tiny
+// geometries (K < 32). Same tables, same arithmetic, same results.
+//
+// Work item `it` = one channel-block: it = blk * (streams*channels) + sc.
+#pragma once
+
+#include "common.h"
+#include "fft_radix.h"
+#include "pcm.h"
+
+namespace miups {
+
+// ---- sample fetch shared with the fused kernel ---------------------------
+// frame f is relative to the first new input frame of this call; f < 0 reads
+// the carried history (the last hist_frames frames of earlier calls).
+MI_DEVICE float fetch_frame(const Geometry &g, const IoDesc &io, int stream, int ch, long long f) {
+  if (f >= 0) {
+    const char *base = static_cast<const char *>(io.in) + stream * io.in_stream_stride;
+    return pcm_load(base, io.in_fmt, f * io.channels + ch);
+  }
+  const char *base = static_cast<const char *>(io.hist) + stream * io.hist_stream_stride;
+  return pcm_load(base, io.in_fmt, (g.hist_frames + f) * io.channels + ch);
+}
+
+// compact-domain sample n in [0, M) of block blk (reference: timeBuffer
+// assembly, src/vulkan/vulkan_streaming_upsampler.cpp:528-534, with the
+// overlap kept as raw input frames instead of zero-stuffed floats).
+MI_DEVICE float compact_sample(const Geometry &g, const IoDesc &io, int stream, int ch, int blk, int n) {
+  const long long pos = static_cast<long long>(blk) * g.Bc + n - g.Oc;
+  if (g.S == 1) {
+    return fetch_frame(g, io, stream, ch, pos);
+  }
+  long long q = pos / g.S;
+  long long r = pos % g.S;
+  if (r < 0) {
+    r += g.S;
+    q -= 1;
+  }
+  return r == 0 ? fetch_frame(g, io, stream, ch, q) : 0.0f;
+}
+
+// output sample: compact index n (>= Oc) of phase p -> frame blk*B + (n-Oc)*P + p
+MI_DEVICE void store_output(const Geometry &g, const IoDesc &io, int stream, int ch, int blk, int p, int n, float v) {
+  if (n < g.Oc) {
+    return;
+  }
+  const long long frame = static_cast<long long>(blk) * g.B + static_cast<long long>(n - g.Oc) * g.P + p;
+  char *base = static_cast<char *>(io.out) + stream * io.out_stream_stride;
+  pcm_store(base, io.out_fmt, frame * io.channels + ch, v);
+}
+
+// ---- stage 1: z[n'] = x[2n'] + j x[2n'+1] --------------------------------
+MI_GLOBAL void gen_load_kernel(Geometry g, IoDesc io, cf *MI_RESTRICT work, int item0, int nitems) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const long long total = static_cast<long long>(nitems) * g.K;
+  if (gid >= total) {
+    return;
+  }
+  const int it = static_cast<int>(gid / g.K);
+  const int n = static_cast<int>(gid % g.K);
+  const int sc_count = io.streams * io.channels;
+  const int blk = (item0 + it) / sc_count;
+  const int sc = (item0 + it) % sc_count;
+  const int s = sc / io.channels, c = sc % io.channels;
+  work[gid] = mk(compact_sample(g, io, s, c, blk, 2 * n), compact_sample(g, io, s, c, blk, 2 * n + 1));
+}
+
+// ---- stage 2/4: one Stockham radix-R pass over a batch of length-K rows ---
+//   out[(j-k)*R + k + u*Ns] = DFT_R( in[j + t*K/R] * W_{Ns*R}^{t*k} ), k = j mod Ns
+template <int DIR, int R>
+MI_GLOBAL void gen_pass_kernel(const cf *MI_RESTRICT in, cf *MI_RESTRICT out, const cf *MI_RESTRICT tw, int K, int Ns,
+                               int log2NsR, long long rows) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const int per_row = K / R;
+  if (gid >= rows * per_row) {
+    return;
+  }
+  const long long row = gid / per_row;
+  const int j = static_cast<int>(gid % per_row);
+  const cf *src = in + row * K;
+  cf *dst = out + row * K;
+  cf v[R];
+  MI_UNROLL
+  for (int t = 0; t < R; ++t) {
+    v[t] = src[j + t * per_row];
+  }
+  const int k = j & (Ns - 1);
+  if (Ns > 1) {
+    apply_twiddles<DIR, R>(v, tw[tw_offset(log2NsR) + k]);
+  }
+  dftR<DIR, R>(v);
+  const int base = (j - k) * R + k;
+  MI_UNROLL
+  for (int u = 0; u < R; ++u) {
+    dst[base + u * Ns] = v[out_pos<R>(u)];
+  }
+}
+
+// ---- stage 3: untangle (real-FFT split), multiply by the phase spectra,
+// re-tangle for the packed inverse. Per bin k of phase p:
+//   u = Z[k], v = conj Z[(K-k) mod K], W = W_M^k
+//   Xa = (u+v) - jW(u-v)          (= 2 X[k])
+//   Xb = (u+v) + jW(u-v)          (= 2 conj X[K-k])
+//   P = Xa * Gs_p[k],  Q = Xb * Gc_p[k]          Gs = G/(2M), Gc[k] = conj Gs[K-k]
+//   Z'_p[k] = (P+Q) + j conj(W) (P-Q)
+// This is the reference's `freq[i] *= filterSpectrum_[i]`
+// (vulkan_streaming_upsampler.cpp:553-558,583-585) in the polyphase basis.
+MI_DEVICE cf spectral_bin(cf u, cf zm, cf W, cf gs, cf gc) {
+  const cf v = cconj(zm);
+  const cf s = cadd(u, v);
+  const cf d = cmulj(cmul(W, csub(u, v)));
+  const cf P = cmul(csub(s, d), gs);
+  const cf Q = cmul(cadd(s, d), gc);
+  return cadd(cadd(P, Q), cmulj(cmulc(csub(P, Q), W)));
+}
+
+MI_GLOBAL void gen_multiply_kernel(Geometry g, const cf *MI_RESTRICT Z, cf *MI_RESTRICT Zp, const cf *MI_RESTRICT Gs,
+                                   const cf *MI_RESTRICT Gc, const cf *MI_RESTRICT Wm, int nitems) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const long long total = static_cast<long long>(nitems) * g.K;
+  if (gid >= total) {
+    return;
+  }
+  const long long it = gid / g.K;
+  const int k = static_cast<int>(gid % g.K);
+  const cf u = Z[it * g.K + k];
+  const cf zm = Z[it * g.K + ((g.K - k) & (g.K - 1))];
+  const cf W = Wm[k];
+  for (int p = 0; p < g.P; ++p) {
+    Zp[(it * g.P + p) * g.K + k] =
+        spectral_bin(u, zm, W, Gs[static_cast<long long>(p) * g.K + k], Gc[static_cast<long long>(p) * g.K + k]);
+  }
+}
+
+// ---- stage 5: overlap-discard + phase interleave + PCM store --------------
+// (reference: output[i] = Re freq[overlap + i], :566-569 / :588-591)
+MI_GLOBAL void gen_store_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT y, int item0, int nitems) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const long long total = static_cast<long long>(nitems) * g.P * g.K;
+  if (gid >= total) {
+    return;
+  }
+  const int n = static_cast<int>(gid % g.K);
+  const long long ip = gid / g.K;
+  const int p = static_cast<int>(ip % g.P);
+  const int it = static_cast<int>(ip / g.P);
+  if (2 * n + 1 < g.Oc) {
+    return;
+  }
+  const int sc_count = io.streams * io.channels;
+  const int blk = (item0 + it) / sc_count;
+  const int sc = (item0 + it) % sc_count;
+  const int s = sc / io.channels, c = sc % io.channels;
+  const cf v = y[gid];
+  store_output(g, io, s, c, blk, p, 2 * n, v.x);
+  store_output(g, io, s, c, blk, p, 2 * n + 1, v.y);
+}
+
+// ---- history carry: new_hist = last hist_frames frames of (hist ++ input) --
+// (reference: overlap_.assign(timeBuffer.end() - overlap, ...), :571-572)
+MI_GLOBAL void update_history_kernel(Geometry g, IoDesc io, void *MI_RESTRICT new_hist, long long total_in_frames) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const int bytes = pcm_bytes(io.in_fmt);
+  const long long row_bytes = static_cast<long long>(g.hist_frames) * io.channels * bytes;
+  if (gid >= row_bytes * io.streams) {
+    return;
+  }
+  const int s = static_cast<int>(gid / row_bytes);
+  const long long off = gid % row_bytes;
+  const long long frame_bytes = static_cast<long long>(io.channels) * bytes;
+  const long long i = off / frame_bytes;       // frame within new history
+  const long long within = off % frame_bytes;  // byte within frame
+  const long long f = total_in_frames - g.hist_frames + i;
+  unsigned char b;
+  if (f >= 0) {
+    b = static_cast<const unsigned char *>(io.in)[s * io.in_stream_stride + f * frame_bytes + within];
+  } else {
+    b = static_cast<const unsigned char *>(io.hist)[s * io.hist_stream_stride + (g.hist_frames + f) * frame_bytes + within];
+  }
+  static_cast<unsigned char *>(new_hist)[s * io.hist_stream_stride + off] = b;
+}
+
+}  // namespace miups

@@ -1,0 +1,160 @@
+#include "spectrum.h"
+
+#include <cmath>
+
+#include "../device/fft_radix.h"
+#include "host_fft.h"
+
+namespace miups {
+namespace {
+
+int Log2(std::size_t v) {
+  int r = 0;
+  while ((static_cast<std::size_t>(1) << r) < v) {
+    ++r;
+  }
+  return r;
+}
+
+}  // namespace
+
+bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage) {
+  const std::size_t N = config.fftSize, B = config.blockSize;
+  const std::size_t L = config.upsampleFactor > 1 ? config.upsampleFactor : 1;
+  if (N < 2 || B == 0 || B >= N || (N & (N - 1)) != 0 || B % L != 0) {
+    if (errorMessage) {
+      *errorMessage = "invalid filter geometry";
+    }
+    return false;
+  }
+  if (N > (static_cast<std::size_t>(1) << 28)) {
+    if (errorMessage) {
+      *errorMessage = "fft_size too large";
+    }
+    return false;
+  }
+  // Frequency-domain polyphase needs the whole time buffer to be an L-fold
+  // zero-stuffing of a compact sequence, i.e. L | N (then L | O too because
+  // L | B). Otherwise (non power-of-two factors) keep the stuffing in the time
+  // domain: P = 1, S = L. Same kernels, same formulas.
+  const std::size_t P = (N % L == 0) ? L : 1;
+  const std::size_t S = L / P;
+  const std::size_t O = N - B;
+  geo->P = static_cast<int>(P);
+  geo->S = static_cast<int>(S);
+  geo->M = static_cast<int>(N / P);
+  geo->K = geo->M / 2;
+  geo->log2k = Log2(static_cast<std::size_t>(geo->K));
+  geo->Oc = static_cast<int>(O / P);
+  geo->Bc = static_cast<int>(B / P);
+  geo->n_in = static_cast<int>(B / L);
+  geo->B = static_cast<int>(B);
+  geo->hist_frames = static_cast<int>((static_cast<std::size_t>(geo->Oc) + S - 1) / S);
+  return true;
+}
+
+bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
+                 const std::vector<std::complex<double>> *eq_half, int flags, FilterTables *out,
+                 std::string *errorMessage) {
+  if (!BuildGeometry(config, &out->geo, errorMessage)) {
+    return false;
+  }
+  const Geometry &g = out->geo;
+  const std::size_t N = config.fftSize;
+  const int P = g.P, M = g.M, K = g.K;
+  if (taps.size() != config.taps || taps.size() > N) {
+    if (errorMessage) {
+      *errorMessage = "taps must be <= fft_size for minimal overlap-save";
+    }
+    return false;
+  }
+  if (eq_half && eq_half->size() != N / 2 + 1) {
+    if (errorMessage) {
+      *errorMessage = "EQ response must cover bins 0..fft_size/2";
+    }
+    return false;
+  }
+
+  // ---- total impulse response on the N-point circle -----------------------
+  std::vector<double> h(N, 0.0);
+  const bool compat = (flags & kLoadRefCompatSpectrum) != 0;
+  if (!eq_half && !compat) {
+    for (std::size_t i = 0; i < taps.size(); ++i) {
+      h[i] = static_cast<double>(taps[i]);
+    }
+  } else {
+    std::vector<std::complex<double>> H(N);
+    if (compat) {
+      std::vector<std::complex<float>> H32(N, std::complex<float>(0.0f, 0.0f));
+      for (std::size_t i = 0; i < taps.size(); ++i) {
+        H32[i] = std::complex<float>(taps[i], 0.0f);
+      }
+      FftRefCompat32(H32, false);
+      for (std::size_t i = 0; i < N; ++i) {
+        H[i] = std::complex<double>(H32[i].real(), H32[i].imag());
+      }
+    } else {
+      for (std::size_t i = 0; i < N; ++i) {
+        H[i] = i < taps.size() ? std::complex<double>(taps[i], 0.0) : std::complex<double>(0.0, 0.0);
+      }
+      Fft64(H, false);
+    }
+    if (eq_half) {
+      const auto &e = *eq_half;
+      for (std::size_t k = 0; k < N; ++k) {
+        std::complex<double> r;
+        if (k == 0 || k == N / 2) {
+          r = std::complex<double>(e[k].real(), 0.0);
+        } else if (k < N / 2) {
+          r = e[k];
+        } else {
+          r = std::conj(e[N - k]);
+        }
+        H[k] *= r;
+      }
+    }
+    // The reference keeps Re(IFFT(X*H)); for real x that equals filtering with
+    // the real part of IFFT(H), whatever asymmetry rounding left in H.
+    Fft64(H, true);
+    for (std::size_t i = 0; i < N; ++i) {
+      h[i] = H[i].real();
+    }
+  }
+
+  // ---- phase spectra -------------------------------------------------------
+  out->Gs.assign(static_cast<std::size_t>(P) * K, cf{0.0f, 0.0f});
+  out->Gc.assign(static_cast<std::size_t>(P) * K, cf{0.0f, 0.0f});
+  const double scale = 1.0 / (2.0 * static_cast<double>(M));
+  std::vector<std::complex<double>> G(M);
+  for (int p = 0; p < P; ++p) {
+    for (int i = 0; i < M; ++i) {
+      G[i] = std::complex<double>(h[static_cast<std::size_t>(i) * P + p], 0.0);
+    }
+    Fft64(G, false);
+    for (int k = 0; k < K; ++k) {
+      const std::complex<double> a = G[k] * scale;
+      const std::complex<double> b = std::conj(G[K - k]) * scale;
+      out->Gs[static_cast<std::size_t>(p) * K + k] = cf{static_cast<float>(a.real()), static_cast<float>(a.imag())};
+      out->Gc[static_cast<std::size_t>(p) * K + k] = cf{static_cast<float>(b.real()), static_cast<float>(b.imag())};
+    }
+  }
+
+  // ---- twiddles --------------------------------------------------------------
+  const double pi = 3.14159265358979323846264338327950288;
+  out->Wm.resize(K);
+  for (int k = 0; k < K; ++k) {
+    const double a = -2.0 * pi * static_cast<double>(k) / static_cast<double>(M);
+    out->Wm[k] = cf{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+  }
+  out->tw.assign(K > 1 ? K - 1 : 1, cf{1.0f, 0.0f});
+  for (int q = 1; q <= g.log2k; ++q) {
+    const int half = 1 << (q - 1);
+    for (int k = 0; k < half; ++k) {
+      const double a = -2.0 * pi * static_cast<double>(k) / static_cast<double>(1 << q);
+      out->tw[tw_offset(q) + k] = cf{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+    }
+  }
+  return true;
+}
+
+}  // namespace miups

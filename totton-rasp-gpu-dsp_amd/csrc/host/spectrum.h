@@ -1,0 +1,39 @@
+// Load-time construction of everything the kernels read besides audio:
+// geometry, polyphase filter spectra (with the EQ folded in), twiddles.
+// Runs on the host in fp64, once per LoadFilter / EQ change
+// (reference counterpart: PrepareSpectrum, vulkan_streaming_upsampler.cpp:726-753).
+#pragma once
+
+#include <complex>
+#include <string>
+#include <vector>
+
+#include "../device/common.h"
+#include "filter_config.h"
+
+namespace miups {
+
+enum LoadFlags : int {
+  kLoadDefault = 0,
+  // Build the spectrum from the reference's own fp32 recurrence-twiddle FFT of
+  // the taps (what both reference paths multiply by), instead of the exact one.
+  kLoadRefCompatSpectrum = 1,
+};
+
+struct FilterTables {
+  Geometry geo{};
+  std::vector<cf> Gs;  // [P][K]  G_p[k] / (2M)
+  std::vector<cf> Gc;  // [P][K]  conj(G_p[K-k]) / (2M)   (index 0 holds the Nyquist bin)
+  std::vector<cf> Wm;  // [K]     exp(-2 pi i k / M)
+  std::vector<cf> tw;  // see tw_offset() in device/fft_radix.h
+};
+
+bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage);
+
+// eq_half: optional response on bins 0..N/2 of the N-point grid (fp64); the
+// total spectrum is H_fir[k] * EQ[k] on all N bins (Hermitian extension).
+bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
+                 const std::vector<std::complex<double>> *eq_half, int flags, FilterTables *out,
+                 std::string *errorMessage);
+
+}  // namespace miups
