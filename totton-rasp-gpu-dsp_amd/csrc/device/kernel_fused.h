@@ -24,12 +24,27 @@
 // owns butterfly sets S_tau and S_{J-tau} (J = K/16), which are mirror images
 // under k -> K-k, so the untangle needs no data from another thread. Thread 0
 // owns the two self-mirrored sets S_0 and S_{J/2}.
+//
+// PCM formats are a run-time property of the engine; the format switch is
+// hoisted around the first forward pass and the last inverse pass (the only
+// code that touches PCM), so no per-sample branch is executed.
 #pragma once
 
 #include "common.h"
 #include "fft_radix.h"
 #include "kernels_generic.h"
 #include "pcm.h"
+
+#if defined(MIUPS_HOST_EMU)
+#define MI_SCHED_FENCE()
+#define MI_OPAQUE_VGPR(x)
+#else
+#define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Makes `x` look freshly defined: address arithmetic derived from it cannot be
+// hoisted out of the phase loop (hipcc otherwise precomputes every LDS / output
+// offset and store predicate of all passes and keeps >100 registers live).
+#define MI_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 
 namespace miups {
 
@@ -93,6 +108,55 @@ MI_DEVICE void pair_phase(cf xa, cf xb, cf W, cf gs, cf gc, cf &zk, cf &zkm) {
   zkm = cconj(csub(S, D));
 }
 
+// ---- format-typed sample access (p points AT the sample) -------------------
+template <int FMT>
+MI_DEVICE float sample_load(const char *p) {
+  if constexpr (FMT == kF32) {
+    return *reinterpret_cast<const float *>(p);
+  } else if constexpr (FMT == kS32) {
+    return static_cast<float>(*reinterpret_cast<const int32_t *>(p)) * (1.0f / 2147483648.0f);
+  } else if constexpr (FMT == kS16) {
+    return static_cast<float>(*reinterpret_cast<const int16_t *>(p)) * (1.0f / 32768.0f);
+  } else {
+    return pcm_load(p, kS24_3LE, 0);
+  }
+}
+template <int FMT>
+MI_DEVICE void sample_store(char *p, float v) {
+  pcm_store(p, FMT, 0, v);  // FMT is a constant here: the switch folds away
+}
+
+// Per-workgroup addressing (fused path requires S == 1, so compact sample n of
+// this block is input frame f0 + n, f0 = blk*Bc - Oc; frames < 0 are history).
+struct BlockIo {
+  const char *pin;    // where compact sample 0 would be in `in`   (valid for n >= n_hist)
+  const char *phist;  // where compact sample 0 is in the history  (valid for n <  n_hist)
+  char *pout;         // where compact output 0 of phase 0 would go (valid for n >= Oc)
+  // byte steps; the host only selects the fused path when M * step < 2^31
+  int in_step;   // between consecutive frames of one channel
+  int out_step;  // between consecutive compact outputs of one phase (= P frames)
+  int ph_step;   // between phases (= 1 frame)
+  int n_hist;
+  int Oc;
+};
+
+MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int c, int blk) {
+  BlockIo b;
+  const long long ib = pcm_bytes(io.in_fmt), ob = pcm_bytes(io.out_fmt);
+  const long long f0 = static_cast<long long>(blk) * g.Bc - g.Oc;
+  b.in_step = static_cast<int>(ib * io.channels);
+  b.pin = static_cast<const char *>(io.in) + s * io.in_stream_stride + (f0 * io.channels + c) * ib;
+  b.phist = static_cast<const char *>(io.hist) + s * io.hist_stream_stride +
+            ((g.hist_frames + f0) * io.channels + c) * ib;
+  b.n_hist = f0 >= 0 ? 0 : (-f0 > g.M ? g.M : static_cast<int>(-f0));
+  b.ph_step = static_cast<int>(ob * io.channels);
+  b.out_step = b.ph_step * g.P;
+  b.pout = static_cast<char *>(io.out) + s * io.out_stream_stride +
+           ((static_cast<long long>(blk) * g.B - static_cast<long long>(g.Oc) * g.P) * io.channels + c) * ob;
+  b.Oc = g.Oc;
+  return b;
+}
+
 template <int LOG2K>
 struct FusedCfg {
   static constexpr int K = 1 << LOG2K;
@@ -112,20 +176,39 @@ struct FusedKernel {
   static constexpr int LOG2R0 = Cfg::LOG2R0;
 
   // ---- LDS access for one radix-R butterfly -------------------------------
+  // The swizzle only permutes within aligned groups of 16, so when the element
+  // stride is a multiple of 256 it is the same for every element.
   template <int R>
   static MI_DEVICE void lds_read(const cf *lds, int j, cf *v) {
-    MI_UNROLL
-    for (int t = 0; t < R; ++t) {
-      v[t] = lds[lds_swz(j + t * (K / R))];
+    constexpr int stride = K / R;
+    if constexpr (stride % 256 == 0) {
+      const cf *p = lds + lds_swz(j);
+      MI_UNROLL
+      for (int t = 0; t < R; ++t) {
+        v[t] = p[t * stride];
+      }
+    } else {
+      MI_UNROLL
+      for (int t = 0; t < R; ++t) {
+        v[t] = lds[lds_swz(j + t * stride)];
+      }
     }
   }
   template <int R, int NS>
   static MI_DEVICE void lds_write(cf *lds, int j, const cf *v) {
     const int k = j & (NS - 1);
     const int base = (j - k) * R + k;
-    MI_UNROLL
-    for (int u = 0; u < R; ++u) {
-      lds[lds_swz(base + u * NS)] = v[out_pos<R>(u)];
+    if constexpr (NS % 256 == 0) {
+      cf *p = lds + lds_swz(base);
+      MI_UNROLL
+      for (int u = 0; u < R; ++u) {
+        p[u * NS] = v[out_pos<R>(u)];
+      }
+    } else {
+      MI_UNROLL
+      for (int u = 0; u < R; ++u) {
+        lds[lds_swz(base + u * NS)] = v[out_pos<R>(u)];
+      }
     }
   }
   template <int DIR, int R, int NS, int LOG2NSR>
@@ -137,81 +220,148 @@ struct FusedKernel {
   }
 
   // ---- global load of one radix-R butterfly's inputs (forward pass 0) -----
-  template <int R>
-  static MI_DEVICE void global_read(const Geometry &g, const IoDesc &io, int s, int c, int blk, int j, cf *v) {
+  // kHist = false: the whole block lies in `in` (true for all but the first
+  // blocks of a call), one uniform base + 32-bit offsets.
+  template <int FMT, int R, bool kHist>
+  static MI_DEVICE void global_read(const BlockIo &b, int j, cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
-      const int n = j + t * (K / R);
-      v[t] = mk(compact_sample(g, io, s, c, blk, 2 * n), compact_sample(g, io, s, c, blk, 2 * n + 1));
+      const int n = 2 * (j + t * (K / R));
+      const unsigned o0 = static_cast<unsigned>(n) * static_cast<unsigned>(b.in_step);
+      const unsigned o1 = o0 + static_cast<unsigned>(b.in_step);
+      if constexpr (kHist) {
+        const char *p0 = (n < b.n_hist ? b.phist : b.pin) + o0;
+        const char *p1 = (n + 1 < b.n_hist ? b.phist : b.pin) + o1;
+        v[t] = mk(sample_load<FMT>(p0), sample_load<FMT>(p1));
+      } else {
+        v[t] = mk(sample_load<FMT>(b.pin + o0), sample_load<FMT>(b.pin + o1));
+      }
     }
   }
   // ---- global store of one radix-R butterfly's outputs (inverse last pass) -
-  template <int R>
-  static MI_DEVICE void global_write(const Geometry &g, const IoDesc &io, int s, int c, int blk, int p, int j,
-                                     const cf *v) {
+  // overlap-discard (:566-569): compact samples n < Oc are dropped.
+  template <int FMT, int R>
+  static MI_DEVICE void global_write(const BlockIo &b, char *pout_p, int j, const cf *v) {
     MI_UNROLL
     for (int u = 0; u < R; ++u) {
-      const int n = j + u * (K / R);
+      const int n = 2 * (j + u * (K / R));
       const cf y = v[out_pos<R>(u)];
-      store_output(g, io, s, c, blk, p, 2 * n, y.x);
-      store_output(g, io, s, c, blk, p, 2 * n + 1, y.y);
+      const unsigned o0 = static_cast<unsigned>(n) * static_cast<unsigned>(b.out_step);
+      if (n >= b.Oc) {
+        sample_store<FMT>(pout_p + o0, y.x);
+      }
+      if (n + 1 >= b.Oc) {
+        sample_store<FMT>(pout_p + (o0 + static_cast<unsigned>(b.out_step)), y.y);
+      }
     }
   }
 
-  // forward radix-16 pass number P16 (0-based among the radix-16 passes)
+  // ---- forward pass 0 when it is a radix-R0 pass (R0 > 1) -------------------
+  template <int FMT, bool kHist>
+  static MI_DEVICE void fwd_r0_impl(const BlockIo &b, cf *lds, int tid) {
+    MI_UNROLL
+    for (int i = 0; i < 32 / R0; ++i) {
+      const int j = tid + i * T;
+      cf v[R0];
+      global_read<FMT, R0, kHist>(b, j, v);
+      dftR<-1, R0>(v);
+      lds_write<R0, 1>(lds, j, v);
+    }
+  }
+  template <int FMT>
+  static MI_DEVICE void fwd_r0(const BlockIo &b, cf *lds, int tid) {
+    if (b.n_hist == 0) {
+      fwd_r0_impl<FMT, false>(b, lds, tid);
+    } else {
+      fwd_r0_impl<FMT, true>(b, lds, tid);
+    }
+  }
+  // ---- forward pass 0 when it is a radix-16 pass (R0 == 1, N16 >= 2) --------
+  template <int FMT>
+  static MI_DEVICE void fwd16_from_global(const BlockIo &b, cf *lds, int tid, cf *A, cf *B) {
+    if (b.n_hist == 0) {
+      global_read<FMT, 16, false>(b, tid, A);
+      global_read<FMT, 16, false>(b, tid + T, B);
+    } else {
+      global_read<FMT, 16, true>(b, tid, A);
+      global_read<FMT, 16, true>(b, tid + T, B);
+    }
+    dft16<-1>(A);
+    lds_write<16, 1>(lds, tid, A);
+    dft16<-1>(B);
+    lds_write<16, 1>(lds, tid + T, B);
+  }
+
+  // forward radix-16 pass P16 reading LDS (every pass except a global pass 0)
   template <int P16>
-  static MI_DEVICE void fwd16(const Geometry &g, const IoDesc &io, int s, int c, int blk, cf *lds, const cf *tw,
-                              int tid, cf *A, cf *B) {
+  static MI_DEVICE void fwd16(cf *lds, const cf *tw, int tid, cf *A, cf *B) {
     constexpr int NS = R0 * (1 << (4 * P16));
     constexpr int LOG2NSR = LOG2R0 + 4 * P16 + 4;
-    constexpr bool kFromGlobal = (R0 == 1 && P16 == 0);
     constexpr bool kLast = (P16 == N16 - 1);
     const int jA = tid;
     const int jB = kLast ? (tid == 0 ? T : J - tid) : tid + T;
-    if constexpr (kFromGlobal) {
-      global_read<16>(g, io, s, c, blk, jA, A);
-      global_read<16>(g, io, s, c, blk, jB, B);
-    } else {
-      lds_read<16>(lds, jA, A);
-      lds_read<16>(lds, jB, B);
-      MI_SYNC();  // every read of this pass done before anyone overwrites
-    }
+    lds_read<16>(lds, jA, A);
+    lds_read<16>(lds, jB, B);
+    MI_SYNC();  // every read of this pass done before anyone overwrites
     butterfly<-1, 16, NS, LOG2NSR>(A, jA, tw);
-    butterfly<-1, 16, NS, LOG2NSR>(B, jB, tw);
     if constexpr (!kLast) {
       lds_write<16, NS>(lds, jA, A);
+    }
+    MI_SCHED_FENCE();
+    butterfly<-1, 16, NS, LOG2NSR>(B, jB, tw);
+    if constexpr (!kLast) {
       lds_write<16, NS>(lds, jB, B);
       MI_SYNC();
     }
   }
 
-  // inverse radix-16 pass number P16; pass 0 takes its inputs from A/B
+  // inverse radix-16 pass P16 that ends in LDS; pass 0 takes its inputs from A/B
   template <int P16>
-  static MI_DEVICE void inv16(const Geometry &g, const IoDesc &io, int s, int c, int blk, int p, cf *lds,
-                              const cf *tw, int tid, cf *A, cf *B) {
+  static MI_DEVICE void inv16(cf *lds, const cf *tw, int tid, cf *A, cf *B) {
     constexpr int NS = 1 << (4 * P16);
     constexpr int LOG2NSR = 4 * P16 + 4;
     constexpr bool kFirst = (P16 == 0);
-    constexpr bool kToGlobal = (R0 == 1 && P16 == N16 - 1);
     const int jA = tid;
     const int jB = kFirst ? (tid == 0 ? T : J - tid) : tid + T;
     if constexpr (!kFirst) {
       lds_read<16>(lds, jA, A);
       lds_read<16>(lds, jB, B);
-      if constexpr (!kToGlobal) {
-        MI_SYNC();
-      }
+      MI_SYNC();
     }
     butterfly<+1, 16, NS, LOG2NSR>(A, jA, tw);
+    lds_write<16, NS>(lds, jA, A);
+    MI_SCHED_FENCE();
     butterfly<+1, 16, NS, LOG2NSR>(B, jB, tw);
-    if constexpr (kToGlobal) {
-      global_write<16>(g, io, s, c, blk, p, jA, A);
-      global_write<16>(g, io, s, c, blk, p, jB, B);
-      MI_SYNC();  // LDS free for the next phase
-    } else {
-      lds_write<16, NS>(lds, jA, A);
-      lds_write<16, NS>(lds, jB, B);
-      MI_SYNC();
+    lds_write<16, NS>(lds, jB, B);
+    MI_SYNC();
+  }
+  // inverse last pass when it is a radix-16 pass (R0 == 1): LDS -> PCM
+  template <int FMT>
+  static MI_DEVICE void inv16_to_global(const BlockIo &b, char *pout_p, const cf *lds, const cf *tw, int tid, cf *A,
+                                        cf *B) {
+    constexpr int P16 = N16 - 1;
+    constexpr int NS = 1 << (4 * P16);
+    lds_read<16>(lds, tid, A);
+    lds_read<16>(lds, tid + T, B);
+    butterfly<+1, 16, NS, 4 * P16 + 4>(A, tid, tw);
+    global_write<FMT, 16>(b, pout_p, tid, A);
+    MI_SCHED_FENCE();
+    butterfly<+1, 16, NS, 4 * P16 + 4>(B, tid + T, tw);
+    global_write<FMT, 16>(b, pout_p, tid + T, B);
+  }
+  // inverse last pass when it is the radix-R0 pass: LDS -> PCM
+  template <int FMT>
+  static MI_DEVICE void inv_r0_to_global(const BlockIo &b, char *pout_p, const cf *lds, const cf *tw, int tid) {
+    MI_UNROLL
+    for (int i = 0; i < 32 / R0; ++i) {
+      const int j = tid + i * T;
+      cf v[R0];
+      lds_read<R0>(lds, j, v);
+      butterfly<+1, R0, K / R0, LOG2K>(v, j, tw);
+      global_write<FMT, R0>(b, pout_p, j, v);
+      if ((i & 3) == 3) {
+        MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
+      }
     }
   }
 
@@ -223,10 +373,10 @@ struct FusedKernel {
                                      const cf *MI_RESTRICT gc, cf *A, cf *B) {
     if constexpr (!kSelf) {
       // pair t: k = tid + t*J  <->  K-k = (J-tid) + (15-t)*J
+      const cf *ps = gs + tid, *pc = gc + tid;
       MI_UNROLL
       for (int t = 0; t < 16; ++t) {
-        const int k = tid + t * J;
-        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), gs[k], gc[k], A[t], B[15 - t]);
+        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), ps[t * J], pc[t * J], A[t], B[15 - t]);
       }
     } else {
       // set S_0: k = t*J <-> (16-t)*J, t = 0..8 (t = 0 pairs DC with Nyquist
@@ -276,28 +426,34 @@ struct FusedKernel {
     const int sc_count = io.streams * io.channels;
     const int blk = item / sc_count;
     const int sc = item % sc_count;
-    const int s = sc / io.channels, c = sc % io.channels;
+    const BlockIo b = make_block_io(g, io, sc / io.channels, sc % io.channels, blk);
 
     cf A[16], B[16];
 
     // ------------------------------ forward ------------------------------
     if constexpr (R0 > 1) {
-      MI_UNROLL
-      for (int i = 0; i < 32 / R0; ++i) {
-        const int j = tid + i * T;
-        cf v[R0];
-        global_read<R0>(g, io, s, c, blk, j, v);
-        dftR<-1, R0>(v);
-        lds_write<R0, 1>(lds, j, v);
+      switch (io.in_fmt) {
+        case kS32: fwd_r0<kS32>(b, lds, tid); break;
+        case kF32: fwd_r0<kF32>(b, lds, tid); break;
+        case kS16: fwd_r0<kS16>(b, lds, tid); break;
+        default: fwd_r0<kS24_3LE>(b, lds, tid); break;
+      }
+      MI_SYNC();
+      fwd16<0>(lds, tw, tid, A, B);
+    } else {
+      switch (io.in_fmt) {
+        case kS32: fwd16_from_global<kS32>(b, lds, tid, A, B); break;
+        case kF32: fwd16_from_global<kF32>(b, lds, tid, A, B); break;
+        case kS16: fwd16_from_global<kS16>(b, lds, tid, A, B); break;
+        default: fwd16_from_global<kS24_3LE>(b, lds, tid, A, B); break;
       }
       MI_SYNC();
     }
-    fwd16<0>(g, io, s, c, blk, lds, tw, tid, A, B);
     if constexpr (N16 >= 2) {
-      fwd16<1>(g, io, s, c, blk, lds, tw, tid, A, B);
+      fwd16<1>(lds, tw, tid, A, B);
     }
     if constexpr (N16 >= 3) {
-      fwd16<2>(g, io, s, c, blk, lds, tw, tid, A, B);
+      fwd16<2>(lds, tw, tid, A, B);
     }
 
     // ------------------------- split (once per block) --------------------
@@ -314,29 +470,43 @@ struct FusedKernel {
     for (int p = 0; p < g.P; ++p) {
       const cf *gs = Gs + static_cast<long long>(p) * K;
       const cf *gc = Gc + static_cast<long long>(p) * K;
+      char *pout_p = b.pout + p * b.ph_step;
+      int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
+      MI_OPAQUE_VGPR(tl);
       if (tid == 0) {
-        phase_inputs<true>(tid, Xa, Xb, Wa, Wb, gs, gc, A, B);
+        phase_inputs<true>(tl, Xa, Xb, Wa, Wb, gs, gc, A, B);
       } else {
-        phase_inputs<false>(tid, Xa, Xb, Wa, Wb, gs, gc, A, B);
+        phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gs, gc, A, B);
       }
-      inv16<0>(g, io, s, c, blk, p, lds, tw, tid, A, B);
-      if constexpr (N16 >= 2) {
-        inv16<1>(g, io, s, c, blk, p, lds, tw, tid, A, B);
+      constexpr int kLdsInv = (R0 > 1) ? N16 : N16 - 1;  // inverse radix-16 passes that end in LDS
+      if constexpr (kLdsInv >= 1) {
+        inv16<0>(lds, tw, tl, A, B);
       }
-      if constexpr (N16 >= 3) {
-        inv16<2>(g, io, s, c, blk, p, lds, tw, tid, A, B);
+      if constexpr (kLdsInv >= 2) {
+        MI_OPAQUE_VGPR(tl);
+        inv16<1>(lds, tw, tl, A, B);
       }
+      if constexpr (kLdsInv >= 3) {
+        MI_OPAQUE_VGPR(tl);
+        inv16<2>(lds, tw, tl, A, B);
+      }
+      MI_OPAQUE_VGPR(tl);
       if constexpr (R0 > 1) {
-        MI_UNROLL
-        for (int i = 0; i < 32 / R0; ++i) {
-          const int j = tid + i * T;
-          cf v[R0];
-          lds_read<R0>(lds, j, v);
-          butterfly<+1, R0, K / R0, LOG2K>(v, j, tw);
-          global_write<R0>(g, io, s, c, blk, p, j, v);
+        switch (io.out_fmt) {
+          case kS32: inv_r0_to_global<kS32>(b, pout_p, lds, tw, tl); break;
+          case kF32: inv_r0_to_global<kF32>(b, pout_p, lds, tw, tl); break;
+          case kS16: inv_r0_to_global<kS16>(b, pout_p, lds, tw, tl); break;
+          default: inv_r0_to_global<kS24_3LE>(b, pout_p, lds, tw, tl); break;
         }
-        MI_SYNC();  // LDS free for the next phase
+      } else {
+        switch (io.out_fmt) {
+          case kS32: inv16_to_global<kS32>(b, pout_p, lds, tw, tl, A, B); break;
+          case kF32: inv16_to_global<kF32>(b, pout_p, lds, tw, tl, A, B); break;
+          case kS16: inv16_to_global<kS16>(b, pout_p, lds, tw, tl, A, B); break;
+          default: inv16_to_global<kS24_3LE>(b, pout_p, lds, tw, tl, A, B); break;
+        }
       }
+      MI_SYNC();  // LDS free for the next phase
     }
   }
 };

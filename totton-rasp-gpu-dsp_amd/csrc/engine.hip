@@ -176,7 +176,12 @@ bool DispatchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, u
   }
 }
 
-bool FusedCovers(const Geometry &g) { return g.S == 1 && g.log2k >= 5 && g.log2k <= 14; }
+// The fused kernel addresses samples with 32-bit byte offsets from per-block bases.
+bool FusedCovers(const Geometry &g, int channels, int inFmt, int outFmt) {
+  const long long inSpan = static_cast<long long>(g.M) * channels * pcm_bytes(inFmt);
+  const long long outSpan = static_cast<long long>(g.M) * g.P * channels * pcm_bytes(outFmt);
+  return g.S == 1 && g.log2k >= 5 && g.log2k <= 14 && inSpan < (1ll << 31) && outSpan < (1ll << 31);
+}
 
 }  // namespace
 
@@ -339,7 +344,7 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->inFmt_ = inFmt;
   e->outFmt_ = outFmt;
   const Geometry &g = e->filter_->geometry();
-  e->fused_ = FusedCovers(g);
+  e->fused_ = FusedCovers(g, channels, inFmt, outFmt);
   e->histStride_ = static_cast<std::size_t>(g.hist_frames) * channels * pcm_bytes(inFmt);
   const std::size_t bytes = std::max<std::size_t>(e->histStride_ * streams, 16);
   for (int i = 0; i < 2; ++i) {
