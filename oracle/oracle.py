@@ -287,14 +287,23 @@ def pcm_to_float(raw: bytes | np.ndarray, fmt: str) -> np.ndarray:
 def float_to_pcm(x: np.ndarray, fmt: str) -> np.ndarray:
     """alsa_common.cpp:87-127: clamp, scale in fp32, truncate toward zero."""
     x = np.asarray(x, dtype=np.float32)
+
+    def clamp(hi):
+        # std::max(-1.0f, std::min(hi, x)) with std::min/max's comparison
+        # semantics: min(a,b) = (b<a)?b:a, max(a,b) = (a<b)?b:a (NaN -> hi)
+        hi = np.float32(hi)
+        with np.errstate(invalid="ignore"):
+            m = np.where(x < hi, x, hi).astype(np.float32)
+            return np.where(np.float32(-1.0) < m, m, np.float32(-1.0)).astype(np.float32)
+
     if fmt == "s16":
-        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999695), x))
+        c = clamp(0.9999695)
         return np.trunc(c * np.float32(32768.0)).astype("<i2").view(np.uint8)
     if fmt == "s32":
-        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999999), x))
+        c = clamp(0.9999999)
         return np.trunc(c * np.float32(2147483648.0)).astype(np.int64).astype("<i4").view(np.uint8)
     if fmt == "s24":
-        c = np.maximum(np.float32(-1.0), np.minimum(np.float32(0.9999999), x))
+        c = clamp(0.9999999)
         v = np.trunc(c * np.float32(8388608.0)).astype(np.int32)
         out = np.empty((v.size, 3), dtype=np.uint8)
         out[:, 0] = v & 0xFF

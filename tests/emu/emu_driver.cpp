@@ -15,6 +15,8 @@
 //   out.bin: [call][stream][frame][channel] samples of out_fmt
 #include <pthread.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -209,7 +211,27 @@ int main(int argc, char **argv) {
     io.blocks = blocks;
     const unsigned items = static_cast<unsigned>(blocks) * streams * channels;
     if (fused) {
-      DispatchFused(g, io, t, items);
+      // same grouping rule as Engine::Create / ProcessDevice
+      int cg = 1;
+      for (int d = 1; d <= 8 && d <= channels; ++d) {
+        if (channels % d == 0) {
+          cg = d;
+        }
+      }
+      const unsigned wgs = static_cast<unsigned>(blocks) * streams * (channels / cg);
+      const unsigned chunk = wgs > 3 ? (wgs + 1) / 2 : wgs;  // exercise the chunked launch (item0 > 0)
+      std::vector<float> scratch(static_cast<size_t>(chunk) * cg * g.B);
+      io.scratch = scratch.data();
+      io.cg = cg;
+      io.groups = channels / cg;
+      io.out_vec_ok = (reinterpret_cast<uintptr_t>(o.data()) % 16 == 0 && outRow % 16 == 0 &&
+                       (static_cast<size_t>(g.B) * channels * 4) % 16 == 0)
+                          ? 1
+                          : 0;
+      for (unsigned w0 = 0; w0 < wgs; w0 += chunk) {
+        io.item0 = static_cast<int>(w0);
+        DispatchFused(g, io, t, std::min(chunk, wgs - w0));
+      }
     } else {
       const size_t row = g.K;
       std::vector<cf> w0(items * row), w1(items * row), w2(items * row * g.P), w3(items * row * g.P);

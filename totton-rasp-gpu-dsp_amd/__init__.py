@@ -22,7 +22,9 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libmi_upsampler.so"
+# MIUPS_LIB: point at another build of the same library (kernel ablation
+# experiments under profiles/); never at anything else.
+LIB_PATH = Path(os.environ["MIUPS_LIB"]) if os.environ.get("MIUPS_LIB") else _PKG / "lib" / "libmi_upsampler.so"
 
 PCM_F32, PCM_S16, PCM_S24_3LE, PCM_S32 = 0, 1, 2, 3
 PCM_NAMES = {"f32": PCM_F32, "s16": PCM_S16, "s24": PCM_S24_3LE, "s32": PCM_S32}

@@ -127,6 +127,16 @@ struct IoDesc {
   int in_fmt;
   int out_fmt;
   int blocks;            // blocks processed by this call
+  // fused path only: one workgroup handles `cg` consecutive channels of one
+  // (block, stream) and stages their phase-planar fp32 results in `scratch`
+  // ([workgroup][channel-in-group][phase][kept sample]) before writing whole
+  // interleaved frames. groups = channels / cg; item0 = first work item of this
+  // launch (launches are chunked so that scratch stays bounded).
+  float *scratch;
+  int cg;
+  int groups;
+  int item0;
+  int out_vec_ok;        // 1 when out base/strides allow 16-byte aligned vector stores
 };
 
 }  // namespace miups

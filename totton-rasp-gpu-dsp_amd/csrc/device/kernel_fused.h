@@ -131,28 +131,22 @@ MI_DEVICE void sample_store(char *p, float v) {
 struct BlockIo {
   const char *pin;    // where compact sample 0 would be in `in`   (valid for n >= n_hist)
   const char *phist;  // where compact sample 0 is in the history  (valid for n <  n_hist)
-  char *pout;         // where compact output 0 of phase 0 would go (valid for n >= Oc)
-  // byte steps; the host only selects the fused path when M * step < 2^31
-  int in_step;   // between consecutive frames of one channel
-  int out_step;  // between consecutive compact outputs of one phase (= P frames)
-  int ph_step;   // between phases (= 1 frame)
+  // byte step between consecutive frames of one channel; the host only selects
+  // the fused path when M * step < 2^31
+  int in_step;
   int n_hist;
   int Oc;
 };
 
 MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int c, int blk) {
   BlockIo b;
-  const long long ib = pcm_bytes(io.in_fmt), ob = pcm_bytes(io.out_fmt);
+  const long long ib = pcm_bytes(io.in_fmt);
   const long long f0 = static_cast<long long>(blk) * g.Bc - g.Oc;
   b.in_step = static_cast<int>(ib * io.channels);
   b.pin = static_cast<const char *>(io.in) + s * io.in_stream_stride + (f0 * io.channels + c) * ib;
   b.phist = static_cast<const char *>(io.hist) + s * io.hist_stream_stride +
             ((g.hist_frames + f0) * io.channels + c) * ib;
   b.n_hist = f0 >= 0 ? 0 : (-f0 > g.M ? g.M : static_cast<int>(-f0));
-  b.ph_step = static_cast<int>(ob * io.channels);
-  b.out_step = b.ph_step * g.P;
-  b.pout = static_cast<char *>(io.out) + s * io.out_stream_stride +
-           ((static_cast<long long>(blk) * g.B - static_cast<long long>(g.Oc) * g.P) * io.channels + c) * ob;
   b.Oc = g.Oc;
   return b;
 }
@@ -238,20 +232,28 @@ struct FusedKernel {
       }
     }
   }
-  // ---- global store of one radix-R butterfly's outputs (inverse last pass) -
-  // overlap-discard (:566-569): compact samples n < Oc are dropped.
-  template <int FMT, int R>
-  static MI_DEVICE void global_write(const BlockIo &b, char *pout_p, int j, const cf *v) {
+  // ---- store of one radix-R butterfly's outputs (inverse last pass) ---------
+  // overlap-discard (:566-569): compact samples n < Oc are dropped; the kept
+  // ones go, still fp32 and phase-planar, to this workgroup's staging plane
+  // (plane[i] = y_p[Oc + i]) with lane-contiguous 8-byte stores. The epilogue
+  // turns the planes into interleaved PCM frames.
+  template <int R, bool kEvenOc>
+  static MI_DEVICE void plane_write(float *plane, int Oc, int j, const cf *v) {
     MI_UNROLL
     for (int u = 0; u < R; ++u) {
       const int n = 2 * (j + u * (K / R));
       const cf y = v[out_pos<R>(u)];
-      const unsigned o0 = static_cast<unsigned>(n) * static_cast<unsigned>(b.out_step);
-      if (n >= b.Oc) {
-        sample_store<FMT>(pout_p + o0, y.x);
-      }
-      if (n + 1 >= b.Oc) {
-        sample_store<FMT>(pout_p + (o0 + static_cast<unsigned>(b.out_step)), y.y);
+      if constexpr (kEvenOc) {
+        if (n >= Oc) {
+          *reinterpret_cast<cf *>(plane + (n - Oc)) = y;
+        }
+      } else {
+        if (n >= Oc) {
+          plane[n - Oc] = y.x;
+        }
+        if (n + 1 >= Oc) {
+          plane[n + 1 - Oc] = y.y;
+        }
       }
     }
   }
@@ -335,33 +337,112 @@ struct FusedKernel {
     lds_write<16, NS>(lds, jB, B);
     MI_SYNC();
   }
-  // inverse last pass when it is a radix-16 pass (R0 == 1): LDS -> PCM
-  template <int FMT>
-  static MI_DEVICE void inv16_to_global(const BlockIo &b, char *pout_p, const cf *lds, const cf *tw, int tid, cf *A,
-                                        cf *B) {
+  // inverse last pass when it is a radix-16 pass (R0 == 1): LDS -> staging plane
+  template <bool kEvenOc>
+  static MI_DEVICE void inv16_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid, cf *A, cf *B) {
     constexpr int P16 = N16 - 1;
     constexpr int NS = 1 << (4 * P16);
     lds_read<16>(lds, tid, A);
     lds_read<16>(lds, tid + T, B);
     butterfly<+1, 16, NS, 4 * P16 + 4>(A, tid, tw);
-    global_write<FMT, 16>(b, pout_p, tid, A);
+    plane_write<16, kEvenOc>(plane, Oc, tid, A);
     MI_SCHED_FENCE();
     butterfly<+1, 16, NS, 4 * P16 + 4>(B, tid + T, tw);
-    global_write<FMT, 16>(b, pout_p, tid + T, B);
+    plane_write<16, kEvenOc>(plane, Oc, tid + T, B);
   }
-  // inverse last pass when it is the radix-R0 pass: LDS -> PCM
-  template <int FMT>
-  static MI_DEVICE void inv_r0_to_global(const BlockIo &b, char *pout_p, const cf *lds, const cf *tw, int tid) {
+  // inverse last pass when it is the radix-R0 pass: LDS -> staging plane
+  template <bool kEvenOc>
+  static MI_DEVICE void inv_r0_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
     MI_UNROLL
     for (int i = 0; i < 32 / R0; ++i) {
       const int j = tid + i * T;
       cf v[R0];
       lds_read<R0>(lds, j, v);
       butterfly<+1, R0, K / R0, LOG2K>(v, j, tw);
-      global_write<FMT, R0>(b, pout_p, j, v);
+      plane_write<R0, kEvenOc>(plane, Oc, j, v);
       if ((i & 3) == 3) {
         MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
       }
+    }
+  }
+
+  // ---- epilogue: staging planes -> interleaved PCM frames ---------------------
+  // scr[(cc*P + p)*Bc + i] = y_p[Oc + i] of channel c0+cc; output frame
+  // blk*B + i*P + p, channel c0+cc (reference: interleave + ConvertFloatToPcm,
+  // alsa_streamer_main.cpp:327-329,550-552; alsa_common.cpp:87-127).
+  //
+  // Fast form (this group is the whole frame, 4-byte samples, 16-byte aligned):
+  // a thread gathers VPT = cg*pg values (pg consecutive phases of one i, every
+  // channel) = VPT consecutive output samples and writes them as 16-byte vectors;
+  // consecutive lanes write consecutive memory.
+  template <int FMT, int VPT>
+  static MI_DEVICE void epilogue_vec(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
+    const int cg = io.cg, pg = VPT / cg, qn = g.P / pg;
+    const int units = g.Bc * qn;
+    for (int unit = tid; unit < units; unit += T) {
+      const int i = unit / qn, q = unit - i * qn;
+      float v[VPT];
+      MI_UNROLL
+      for (int e = 0; e < VPT; ++e) {
+        const int pp = e / cg, cc = e - pp * cg;
+        v[e] = scr[(cc * g.P + q * pg + pp) * g.Bc + i];
+      }
+      char *dst = out_blk + static_cast<long long>(unit) * (VPT * 4);
+      MI_UNROLL
+      for (int e = 0; e < VPT; e += 4) {
+        if constexpr (FMT == kF32) {
+          struct alignas(16) F4 { float a, b, c, d; };
+          *reinterpret_cast<F4 *>(dst + 4 * e) = F4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+        } else {
+          struct alignas(16) I4 { int32_t a, b, c, d; };
+          I4 w;
+          w.a = static_cast<int32_t>(pcm_clamp(v[e], 0.9999999f) * 2147483648.0f);
+          w.b = static_cast<int32_t>(pcm_clamp(v[e + 1], 0.9999999f) * 2147483648.0f);
+          w.c = static_cast<int32_t>(pcm_clamp(v[e + 2], 0.9999999f) * 2147483648.0f);
+          w.d = static_cast<int32_t>(pcm_clamp(v[e + 3], 0.9999999f) * 2147483648.0f);
+          *reinterpret_cast<I4 *>(dst + 4 * e) = w;
+        }
+      }
+    }
+  }
+  // General form: one output sample per thread and step, lanes in output order.
+  template <int FMT>
+  static MI_DEVICE void epilogue_scalar(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
+    const int cg = io.cg;
+    const long long total = static_cast<long long>(g.B) * cg;
+    for (long long e = tid; e < total; e += T) {
+      const int m = static_cast<int>(e / cg), cc = static_cast<int>(e - static_cast<long long>(m) * cg);
+      const int i = m / g.P, p = m - i * g.P;
+      pcm_store(out_blk, FMT, static_cast<long long>(m) * io.channels + cc, scr[(cc * g.P + p) * g.Bc + i]);
+    }
+  }
+  static MI_DEVICE void epilogue(const Geometry &g, const IoDesc &io, int s, int c0, int blk, const float *scr, int tid) {
+    const int ob = pcm_bytes(io.out_fmt);
+    char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride +
+                    (static_cast<long long>(blk) * g.B * io.channels + c0) * ob;
+    const int cg = io.cg;
+    const bool pow2 = (cg & (cg - 1)) == 0 && (g.P & (g.P - 1)) == 0;
+    const int pg = pow2 ? (cg * g.P <= 16 ? g.P : (16 / cg > 0 ? 16 / cg : 1)) : 1;
+    const int vpt = cg * pg;
+    const bool vec = pow2 && io.out_vec_ok && cg == io.channels && cg <= 16 && vpt >= 4 &&
+                     (io.out_fmt == kF32 || io.out_fmt == kS32);
+    if (vec) {
+      if (io.out_fmt == kF32) {
+        if (vpt == 4) epilogue_vec<kF32, 4>(g, io, out_blk, scr, tid);
+        else if (vpt == 8) epilogue_vec<kF32, 8>(g, io, out_blk, scr, tid);
+        else epilogue_vec<kF32, 16>(g, io, out_blk, scr, tid);
+      } else {
+        if (vpt == 4) epilogue_vec<kS32, 4>(g, io, out_blk, scr, tid);
+        else if (vpt == 8) epilogue_vec<kS32, 8>(g, io, out_blk, scr, tid);
+        else epilogue_vec<kS32, 16>(g, io, out_blk, scr, tid);
+      }
+      return;
+    }
+    switch (io.out_fmt) {
+      case kS32: epilogue_scalar<kS32>(g, io, out_blk, scr, tid); break;
+      case kF32: epilogue_scalar<kF32>(g, io, out_blk, scr, tid); break;
+      case kS16: epilogue_scalar<kS16>(g, io, out_blk, scr, tid); break;
+      default: epilogue_scalar<kS24_3LE>(g, io, out_blk, scr, tid); break;
     }
   }
 
@@ -419,15 +500,11 @@ struct FusedKernel {
     }
   }
 
-  static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm,
-                            const cf *MI_RESTRICT Gs, const cf *MI_RESTRICT Gc, cf *lds) {
-    const int tid = MI_TID_X;
-    const int item = MI_BID_X;
-    const int sc_count = io.streams * io.channels;
-    const int blk = item / sc_count;
-    const int sc = item % sc_count;
-    const BlockIo b = make_block_io(g, io, sc / io.channels, sc % io.channels, blk);
-
+  // One channel-block: forward FFT, split, then per phase multiply + inverse FFT
+  // into this channel's staging planes (scr_c = [P][Bc] floats).
+  static MI_DEVICE void channel_block(const Geometry &g, const IoDesc &io, const BlockIo &b, float *scr_c,
+                                      const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm, const cf *MI_RESTRICT Gs,
+                                      const cf *MI_RESTRICT Gc, cf *lds, int tid) {
     cf A[16], B[16];
 
     // ------------------------------ forward ------------------------------
@@ -467,10 +544,11 @@ struct FusedKernel {
     }
 
     // --------------------------- per output phase ------------------------
+    const bool evenOc = (b.Oc & 1) == 0;
     for (int p = 0; p < g.P; ++p) {
       const cf *gs = Gs + static_cast<long long>(p) * K;
       const cf *gc = Gc + static_cast<long long>(p) * K;
-      char *pout_p = b.pout + p * b.ph_step;
+      float *plane = scr_c + static_cast<long long>(p) * g.Bc;
       int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
       MI_OPAQUE_VGPR(tl);
       if (tid == 0) {
@@ -492,22 +570,43 @@ struct FusedKernel {
       }
       MI_OPAQUE_VGPR(tl);
       if constexpr (R0 > 1) {
-        switch (io.out_fmt) {
-          case kS32: inv_r0_to_global<kS32>(b, pout_p, lds, tw, tl); break;
-          case kF32: inv_r0_to_global<kF32>(b, pout_p, lds, tw, tl); break;
-          case kS16: inv_r0_to_global<kS16>(b, pout_p, lds, tw, tl); break;
-          default: inv_r0_to_global<kS24_3LE>(b, pout_p, lds, tw, tl); break;
+        if (evenOc) {
+          inv_r0_to_plane<true>(plane, b.Oc, lds, tw, tl);
+        } else {
+          inv_r0_to_plane<false>(plane, b.Oc, lds, tw, tl);
         }
       } else {
-        switch (io.out_fmt) {
-          case kS32: inv16_to_global<kS32>(b, pout_p, lds, tw, tl, A, B); break;
-          case kF32: inv16_to_global<kF32>(b, pout_p, lds, tw, tl, A, B); break;
-          case kS16: inv16_to_global<kS16>(b, pout_p, lds, tw, tl, A, B); break;
-          default: inv16_to_global<kS24_3LE>(b, pout_p, lds, tw, tl, A, B); break;
+        if (evenOc) {
+          inv16_to_plane<true>(plane, b.Oc, lds, tw, tl, A, B);
+        } else {
+          inv16_to_plane<false>(plane, b.Oc, lds, tw, tl, A, B);
         }
       }
       MI_SYNC();  // LDS free for the next phase
     }
+  }
+
+  // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
+  static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm,
+                            const cf *MI_RESTRICT Gs, const cf *MI_RESTRICT Gc, cf *lds) {
+    const int tid = MI_TID_X;
+    const int local = MI_BID_X;
+    const int item = io.item0 + local;
+    const int per_blk = io.streams * io.groups;
+    const int blk = item / per_blk;
+    const int rem = item - blk * per_blk;
+    const int s = rem / io.groups;
+    const int c0 = (rem - s * io.groups) * io.cg;
+    float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.B;
+    for (int cc = 0; cc < io.cg; ++cc) {
+      const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
+      int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
+      MI_OPAQUE_VGPR(tc);
+      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, tw, Wm, Gs, Gc, lds, tc);
+    }
+    // every plane store of this workgroup is complete and visible to it
+    // (the loop ends in a workgroup barrier, which carries the release/acquire)
+    epilogue(g, io, s, c0, blk, scr, tid);
   }
 };
 

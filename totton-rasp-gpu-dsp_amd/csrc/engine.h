@@ -90,6 +90,9 @@ class Engine {
   std::shared_ptr<DeviceFilter> filter_;
   int streams_ = 1, channels_ = 1, inFmt_ = kF32, outFmt_ = kF32;
   bool fused_ = false;
+  int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
+  float *scratch_ = nullptr;       // fused path: fp32 staging planes
+  std::size_t scratchBytes_ = 0;
   void *hist_[2] = {nullptr, nullptr};
   int cur_ = 0;
   std::size_t histStride_ = 0;  // bytes per stream

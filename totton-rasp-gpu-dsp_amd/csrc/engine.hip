@@ -309,6 +309,7 @@ Engine::~Engine() {
   }
   (void)hipFree(stageIn_);
   (void)hipFree(stageOut_);
+  (void)hipFree(scratch_);
   for (void *e : evStart_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -345,6 +346,15 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->outFmt_ = outFmt;
   const Geometry &g = e->filter_->geometry();
   e->fused_ = FusedCovers(g, channels, inFmt, outFmt);
+  // channel group per workgroup: the largest divisor of `channels` that is <= 8, so that a
+  // group's samples of one frame are one contiguous run (whole frames when channels <= 8)
+  e->cg_ = 1;
+  for (int d = 1; d <= 8 && d <= channels; ++d) {
+    if (channels % d == 0) {
+      e->cg_ = d;
+    }
+  }
+  e->groups_ = channels / e->cg_;
   e->histStride_ = static_cast<std::size_t>(g.hist_frames) * channels * pcm_bytes(inFmt);
   const std::size_t bytes = std::max<std::size_t>(e->histStride_ * streams, 16);
   for (int i = 0; i < 2; ++i) {
@@ -453,8 +463,32 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
   }
   if (fused_) {
-    if (!DispatchFused(g, io, *filter_, static_cast<unsigned>(items), st, error)) {
-      return false;
+    // one workgroup per (block, stream, channel group); launches are chunked so
+    // that the fp32 staging planes (cg * B floats per workgroup) stay bounded
+    const std::size_t wgs = static_cast<std::size_t>(blocks) * streams_ * groups_;
+    const std::size_t perWg = static_cast<std::size_t>(cg_) * g.B * sizeof(float);
+    const std::size_t budget = static_cast<std::size_t>(1024) << 20;
+    const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(wgs, budget / perWg));
+    if (chunk * perWg > scratchBytes_) {
+      (void)hipFree(scratch_);
+      scratch_ = nullptr;
+      scratchBytes_ = 0;
+      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), chunk * perWg));
+      scratchBytes_ = chunk * perWg;
+    }
+    io.scratch = scratch_;
+    io.cg = cg_;
+    io.groups = groups_;
+    io.out_vec_ok = (reinterpret_cast<std::uintptr_t>(dOut) % 16 == 0 && outStride % 16 == 0 &&
+                     (static_cast<std::size_t>(g.B) * channels_ * 4) % 16 == 0)
+                        ? 1
+                        : 0;
+    for (std::size_t w0 = 0; w0 < wgs; w0 += chunk) {
+      io.item0 = static_cast<int>(w0);
+      const unsigned n = static_cast<unsigned>(std::min<std::size_t>(chunk, wgs - w0));
+      if (!DispatchFused(g, io, *filter_, n, st, error)) {
+        return false;
+      }
     }
   } else {
     const std::size_t perItem = static_cast<std::size_t>(2 + 2 * g.P) * g.K * sizeof(cf);
