@@ -205,10 +205,20 @@ struct FusedKernel {
       }
     }
   }
-  template <int DIR, int R, int NS, int LOG2NSR>
-  static MI_DEVICE void butterfly(cf *v, int j, const cf *tw) {
+  // Twiddle loads are issued at the top of a pass, ahead of the LDS reads and the
+  // barrier, so their L2 round trip overlaps those instead of following them.
+  template <int NS, int LOG2NSR>
+  static MI_DEVICE cf load_tw(const cf *tw, int j) {
     if constexpr (NS > 1) {
-      apply_twiddles<DIR, R>(v, tw[tw_offset(LOG2NSR) + (j & (NS - 1))]);
+      return tw[tw_offset(LOG2NSR) + (j & (NS - 1))];
+    } else {
+      return mk(1.0f, 0.0f);
+    }
+  }
+  template <int DIR, int R, int NS>
+  static MI_DEVICE void butterfly(cf *v, cf w) {
+    if constexpr (NS > 1) {
+      apply_twiddles<DIR, R>(v, w);
     }
     dftR<DIR, R>(v);
   }
@@ -302,15 +312,18 @@ struct FusedKernel {
     constexpr bool kLast = (P16 == N16 - 1);
     const int jA = tid;
     const int jB = kLast ? (tid == 0 ? T : J - tid) : tid + T;
+    const cf wA = load_tw<NS, LOG2NSR>(tw, jA);
+    // jB = jA + T indexes the same entry whenever the table period NS divides T
+    const cf wB = (!kLast && T % NS == 0) ? wA : load_tw<NS, LOG2NSR>(tw, jB);
     lds_read<16>(lds, jA, A);
     lds_read<16>(lds, jB, B);
     MI_SYNC();  // every read of this pass done before anyone overwrites
-    butterfly<-1, 16, NS, LOG2NSR>(A, jA, tw);
+    butterfly<-1, 16, NS>(A, wA);
     if constexpr (!kLast) {
       lds_write<16, NS>(lds, jA, A);
     }
     MI_SCHED_FENCE();
-    butterfly<-1, 16, NS, LOG2NSR>(B, jB, tw);
+    butterfly<-1, 16, NS>(B, wB);
     if constexpr (!kLast) {
       lds_write<16, NS>(lds, jB, B);
       MI_SYNC();
@@ -325,15 +338,17 @@ struct FusedKernel {
     constexpr bool kFirst = (P16 == 0);
     const int jA = tid;
     const int jB = kFirst ? (tid == 0 ? T : J - tid) : tid + T;
+    const cf wA = load_tw<NS, LOG2NSR>(tw, jA);
+    const cf wB = (T % NS == 0) ? wA : load_tw<NS, LOG2NSR>(tw, jB);
     if constexpr (!kFirst) {
       lds_read<16>(lds, jA, A);
       lds_read<16>(lds, jB, B);
       MI_SYNC();
     }
-    butterfly<+1, 16, NS, LOG2NSR>(A, jA, tw);
+    butterfly<+1, 16, NS>(A, wA);
     lds_write<16, NS>(lds, jA, A);
     MI_SCHED_FENCE();
-    butterfly<+1, 16, NS, LOG2NSR>(B, jB, tw);
+    butterfly<+1, 16, NS>(B, wB);
     lds_write<16, NS>(lds, jB, B);
     MI_SYNC();
   }
@@ -342,23 +357,27 @@ struct FusedKernel {
   static MI_DEVICE void inv16_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid, cf *A, cf *B) {
     constexpr int P16 = N16 - 1;
     constexpr int NS = 1 << (4 * P16);
+    const cf wA = load_tw<NS, 4 * P16 + 4>(tw, tid);
+    const cf wB = (T % NS == 0) ? wA : load_tw<NS, 4 * P16 + 4>(tw, tid + T);
     lds_read<16>(lds, tid, A);
     lds_read<16>(lds, tid + T, B);
-    butterfly<+1, 16, NS, 4 * P16 + 4>(A, tid, tw);
+    butterfly<+1, 16, NS>(A, wA);
     plane_write<16, kEvenOc>(plane, Oc, tid, A);
     MI_SCHED_FENCE();
-    butterfly<+1, 16, NS, 4 * P16 + 4>(B, tid + T, tw);
+    butterfly<+1, 16, NS>(B, wB);
     plane_write<16, kEvenOc>(plane, Oc, tid + T, B);
   }
   // inverse last pass when it is the radix-R0 pass: LDS -> staging plane
   template <bool kEvenOc>
   static MI_DEVICE void inv_r0_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
+    // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all 32/R0 butterflies
+    const cf w0 = load_tw<K / R0, LOG2K>(tw, tid);
     MI_UNROLL
     for (int i = 0; i < 32 / R0; ++i) {
       const int j = tid + i * T;
       cf v[R0];
       lds_read<R0>(lds, j, v);
-      butterfly<+1, R0, K / R0, LOG2K>(v, j, tw);
+      butterfly<+1, R0, K / R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
       plane_write<R0, kEvenOc>(plane, Oc, j, v);
       if ((i & 3) == 3) {
         MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
@@ -379,28 +398,43 @@ struct FusedKernel {
   static MI_DEVICE void epilogue_vec(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
     const int cg = io.cg, pg = VPT / cg, qn = g.P / pg;
     const int units = g.Bc * qn;
-    for (int unit = tid; unit < units; unit += T) {
-      const int i = unit / qn, q = unit - i * qn;
-      float v[VPT];
+    // kDepth units per step so that kDepth*VPT plane loads are in flight per lane
+    // (the planes come back from L2 / Infinity Cache, ~1-2 us round trip)
+    constexpr int kDepth = VPT >= 16 ? 2 : 4;
+    for (int base = tid; base < units; base += T * kDepth) {
+      float v[kDepth][VPT];
       MI_UNROLL
-      for (int e = 0; e < VPT; ++e) {
-        const int pp = e / cg, cc = e - pp * cg;
-        v[e] = scr[(cc * g.P + q * pg + pp) * g.Bc + i];
+      for (int d = 0; d < kDepth; ++d) {
+        const int unit = base + d * T;
+        if (unit < units) {
+          const int i = unit / qn, q = unit - i * qn;
+          MI_UNROLL
+          for (int e = 0; e < VPT; ++e) {
+            const int pp = e / cg, cc = e - pp * cg;
+            v[d][e] = scr[(cc * g.P + q * pg + pp) * g.Bc + i];
+          }
+        }
       }
-      char *dst = out_blk + static_cast<long long>(unit) * (VPT * 4);
       MI_UNROLL
-      for (int e = 0; e < VPT; e += 4) {
-        if constexpr (FMT == kF32) {
-          struct alignas(16) F4 { float a, b, c, d; };
-          *reinterpret_cast<F4 *>(dst + 4 * e) = F4{v[e], v[e + 1], v[e + 2], v[e + 3]};
-        } else {
-          struct alignas(16) I4 { int32_t a, b, c, d; };
-          I4 w;
-          w.a = static_cast<int32_t>(pcm_clamp(v[e], 0.9999999f) * 2147483648.0f);
-          w.b = static_cast<int32_t>(pcm_clamp(v[e + 1], 0.9999999f) * 2147483648.0f);
-          w.c = static_cast<int32_t>(pcm_clamp(v[e + 2], 0.9999999f) * 2147483648.0f);
-          w.d = static_cast<int32_t>(pcm_clamp(v[e + 3], 0.9999999f) * 2147483648.0f);
-          *reinterpret_cast<I4 *>(dst + 4 * e) = w;
+      for (int d = 0; d < kDepth; ++d) {
+        const int unit = base + d * T;
+        if (unit < units) {
+          char *dst = out_blk + static_cast<long long>(unit) * (VPT * 4);
+          MI_UNROLL
+          for (int e = 0; e < VPT; e += 4) {
+            if constexpr (FMT == kF32) {
+              struct alignas(16) F4 { float a, b, c, d; };
+              *reinterpret_cast<F4 *>(dst + 4 * e) = F4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
+            } else {
+              struct alignas(16) I4 { int32_t a, b, c, d; };
+              I4 w;
+              w.a = static_cast<int32_t>(pcm_clamp(v[d][e], 0.9999999f) * 2147483648.0f);
+              w.b = static_cast<int32_t>(pcm_clamp(v[d][e + 1], 0.9999999f) * 2147483648.0f);
+              w.c = static_cast<int32_t>(pcm_clamp(v[d][e + 2], 0.9999999f) * 2147483648.0f);
+              w.d = static_cast<int32_t>(pcm_clamp(v[d][e + 3], 0.9999999f) * 2147483648.0f);
+              *reinterpret_cast<I4 *>(dst + 4 * e) = w;
+            }
+          }
         }
       }
     }
