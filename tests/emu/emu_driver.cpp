@@ -122,9 +122,8 @@ cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
 template <int LOG2K>
 void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
-  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() {
-    fused_kernel<LOG2K>(g, io, t.tw.data(), t.Wm.data(), t.Gs.data(), t.Gc.data());
-  });
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb};
+  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K>(g, io, ft); });
 }
 
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {

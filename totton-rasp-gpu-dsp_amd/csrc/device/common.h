@@ -84,6 +84,25 @@ MI_DEVICE cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 MI_DEVICE cf cmulj(cf a) { return mk(-a.y, a.x); }
 MI_DEVICE cf cmulnj(cf a) { return mk(a.y, -a.x); }
 
+struct alignas(16) f4 {
+  float x, y, z, w;
+};
+
+// Tables read by the fused kernel, laid out per thread (the kernel's thread ->
+// frequency-bin assignment is fixed, so the host stores everything in the
+// order lanes consume it: every table load is lane-contiguous).
+//   T = K/32 threads; J = K/16 sixteen-bin sets S_k = {k + t*J}.
+//   thread tau >= 1 owns S_a and S_{J-a}, a = set_of_thread[tau]; thread 0 owns
+//   the self-mirrored S_0 and S_{J/2}.
+struct FusedTables {
+  const cf *tw;        // Stockham/Cooley-Tukey pass twiddles, see tw_offset()
+  const cf *WmT;       // [T]            W_M^a                     (a = low index of the thread's first set)
+  const int *blockB;   // [T]            LDS block that holds the thread's second set after the forward FFT
+  const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau)
+  const f4 *G0;        // [P][17]        thread 0: k = t*J (t = 0..8) then k = J/2 + t*J (t = 0..7)
+  cf Wb;               // W_M^(J/2)
+};
+
 // PCM sample formats at the batched boundary. Values mirror include/mi_upsampler.h.
 enum PcmFormat : int { kF32 = 0, kS16 = 1, kS24_3LE = 2, kS32 = 3 };
 

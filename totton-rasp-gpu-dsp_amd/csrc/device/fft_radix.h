@@ -144,6 +144,41 @@ MI_DEVICE void apply_twiddles(cf *v, cf w) {
   }
 }
 
+// Same powers applied to the OUTPUTS of dftR (decimation in frequency): the
+// u-th output lives at v[out_pos<R>(u)] and is multiplied by w^u.
+template <int DIR, int R>
+MI_DEVICE void apply_twiddles_out(cf *v, cf w) {
+  if (DIR > 0) {
+    w = cconj(w);
+  }
+  v[out_pos<R>(1)] = cmul(v[out_pos<R>(1)], w);
+  if constexpr (R >= 4) {
+    const cf w2 = cmul(w, w);
+    const cf w3 = cmul(w2, w);
+    v[out_pos<R>(2)] = cmul(v[out_pos<R>(2)], w2);
+    v[out_pos<R>(3)] = cmul(v[out_pos<R>(3)], w3);
+    if constexpr (R >= 8) {
+      const cf w4 = cmul(w2, w2);
+      const cf w5 = cmul(w4, w), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+      v[out_pos<R>(4)] = cmul(v[out_pos<R>(4)], w4);
+      v[out_pos<R>(5)] = cmul(v[out_pos<R>(5)], w5);
+      v[out_pos<R>(6)] = cmul(v[out_pos<R>(6)], w6);
+      v[out_pos<R>(7)] = cmul(v[out_pos<R>(7)], w7);
+      if constexpr (R >= 16) {
+        const cf w8 = cmul(w4, w4);
+        v[out_pos<R>(8)] = cmul(v[out_pos<R>(8)], w8);
+        v[out_pos<R>(9)] = cmul(v[out_pos<R>(9)], cmul(w8, w));
+        v[out_pos<R>(10)] = cmul(v[out_pos<R>(10)], cmul(w8, w2));
+        v[out_pos<R>(11)] = cmul(v[out_pos<R>(11)], cmul(w8, w3));
+        v[out_pos<R>(12)] = cmul(v[out_pos<R>(12)], cmul(w8, w4));
+        v[out_pos<R>(13)] = cmul(v[out_pos<R>(13)], cmul(w8, w5));
+        v[out_pos<R>(14)] = cmul(v[out_pos<R>(14)], cmul(w8, w6));
+        v[out_pos<R>(15)] = cmul(v[out_pos<R>(15)], cmul(w8, w7));
+      }
+    }
+  }
+}
+
 // Twiddle table layout: for q = 1..log2k, entries exp(-2*pi*i*k / 2^q) for
 // k in [0, 2^(q-1)) start at offset 2^(q-1) - 1. (Total 2^log2k - 1 entries.)
 MI_HD constexpr int tw_offset(int q) { return (1 << (q - 1)) - 1; }

@@ -1,33 +1,43 @@
 // Fused overlap-save upsampler kernel for gfx950: ONE workgroup = one
-// channel-block, everything between the PCM load and the PCM store stays in
-// registers and LDS.
+// (block, stream, channel group); everything between the PCM load and the PCM
+// store of a channel-block stays in registers and LDS.
 //
 //   load   interleaved PCM frames (history + new) -> z[n] = x[2n] + j x[2n+1]
-//   FFT_K  Stockham radix-(R0,16,..,16), passes staged through LDS (in place,
-//          XOR-swizzled), first pass fed straight from HBM, last pass left in
-//          registers as the butterfly sets {j + t*K/16}
+//   FFT_K  decimation-in-frequency, radices (R0,16,..,16), IN PLACE in LDS
+//          (XOR-swizzled, bank-conflict free): natural order in, digit-reversed
+//          order out; the first pass is fed straight from HBM, the last pass is
+//          left in registers as two sixteen-bin sets {k + t*K/16}
 //   split  real-FFT untangle of mirror pairs (k, K-k), kept in registers
 //   for each output phase p (P = upsample factor):
-//     multiply by the phase spectrum G_p (L2-resident), re-tangle, inverse
-//     FFT_K radix-(16,..,16,R0) through the same LDS buffer, last pass stores
-//     y_p[n], n >= Oc, to out frame (n-Oc)*P + p with the PCM conversion fused.
+//     multiply by the phase spectrum G_p (L2-resident, stored in thread order),
+//     re-tangle, inverse FFT_K decimation-in-time (digit-reversed in, natural
+//     out) through the same LDS buffer; the last pass writes y_p[n], n >= Oc,
+//     phase-planar to the workgroup's fp32 staging planes
+//   epilogue: staging planes of every channel of the group -> whole interleaved
+//     PCM frames, lane-contiguous 16-byte stores.
+//
+// Because every pass is a true in-place butterfly (each thread reads and writes
+// the same LDS words) a pass needs no barrier inside it, only one between
+// passes, and waves drift apart inside a pass so LDS traffic of one wave
+// overlaps butterflies of another.
 //
 // Replaces, per channel-block, the reference's ProcessBlock body
 // (src/vulkan/vulkan_streaming_upsampler.cpp:528-572): zero-stuff/overlap
 // assembly, pack, forward C2C FFT_N, CPU spectral multiply, inverse C2C FFT_N,
-// gather and overlap update -- with N-point transforms replaced by the exact
-// polyphase identity: one K-point forward and P K-point
-// inverse transforms, K = N / (2P).
+// gather and overlap update -- with the N-point transforms replaced by the exact
+// polyphase identity: one K-point forward and P K-point inverse
+// transforms, K = N / (2P).
 //
 // Thread layout: T = K/32 threads, each owns TWO radix-16 butterflies per
-// radix-16 pass. In the two passes adjacent to the spectral stage thread tau
-// owns butterfly sets S_tau and S_{J-tau} (J = K/16), which are mirror images
-// under k -> K-k, so the untangle needs no data from another thread. Thread 0
-// owns the two self-mirrored sets S_0 and S_{J/2}.
+// radix-16 pass. After the forward transform LDS block b (words 16b..16b+15)
+// holds the set S_a = {a + t*K/16}, a = digit-reverse(b). In the two passes
+// adjacent to the spectral stage thread tau owns the blocks of S_a and S_{J-a}
+// (J = K/16), mirror images under k -> K-k, so the untangle needs no data from
+// another thread. Thread 0 owns the self-mirrored S_0 and S_{J/2}.
 //
 // PCM formats are a run-time property of the engine; the format switch is
-// hoisted around the first forward pass and the last inverse pass (the only
-// code that touches PCM), so no per-sample branch is executed.
+// hoisted around the first forward pass and the epilogue (the only code that
+// touches PCM), so no per-sample branch is executed.
 #pragma once
 
 #include "common.h"
@@ -41,14 +51,21 @@
 #else
 #define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Makes `x` look freshly defined: address arithmetic derived from it cannot be
-// hoisted out of the phase loop (hipcc otherwise precomputes every LDS / output
-// offset and store predicate of all passes and keeps >100 registers live).
+// hoisted out of the phase / channel loops (hipcc otherwise precomputes every
+// LDS / output offset of all passes and keeps >100 registers live -> spills).
 #define MI_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace miups {
 
-MI_DEVICE int lds_swz(int i) { return i ^ ((i >> 4) & 15); }
+// LDS word (8-byte complex) index swizzle. Every pass touches, per wave
+// instruction, either 32 consecutive words or 16-word blocks whose block index
+// varies across lanes; the XOR terms spread both patterns over all banks for
+// ds_read_b64 (64 banks, 32-lane groups) and ds_write_b64 (32 banks, 16-lane
+// groups). Verified exhaustively by tests/test_lds_layout.py.
+MI_HD int lds_swz(int i) {
+  return i ^ ((i >> 4) & 15) ^ ((i >> 5) & 8) ^ ((((i >> 8) ^ (i >> 9)) & 1) << 4);
+}
 
 // exp(-2*pi*i*t/32), t = 0..16
 MI_DEVICE cf w32(int t) {
@@ -99,16 +116,16 @@ MI_DEVICE void pair_split(cf u, cf zm, cf W, cf &xa, cf &xb) {
   xb = cadd(s, d);
 }
 //   P = xa*gs, Q = xb*gc ; zk = (P+Q) + j conj(W)(P-Q) ; zkm = conj((P+Q) - j conj(W)(P-Q))
-MI_DEVICE void pair_phase(cf xa, cf xb, cf W, cf gs, cf gc, cf &zk, cf &zkm) {
-  const cf P = cmul(xa, gs);
-  const cf Q = cmul(xb, gc);
+MI_DEVICE void pair_phase(cf xa, cf xb, cf W, f4 g, cf &zk, cf &zkm) {
+  const cf P = cmul(xa, mk(g.x, g.y));
+  const cf Q = cmul(xb, mk(g.z, g.w));
   const cf S = cadd(P, Q);
   const cf D = cmulj(cmulc(csub(P, Q), W));
   zk = cadd(S, D);
   zkm = cconj(csub(S, D));
 }
 
-// ---- format-typed sample access (p points AT the sample) -------------------
+// ---- format-typed sample load (p points AT the sample) ----------------------
 template <int FMT>
 MI_DEVICE float sample_load(const char *p) {
   if constexpr (FMT == kF32) {
@@ -121,13 +138,10 @@ MI_DEVICE float sample_load(const char *p) {
     return pcm_load(p, kS24_3LE, 0);
   }
 }
-template <int FMT>
-MI_DEVICE void sample_store(char *p, float v) {
-  pcm_store(p, FMT, 0, v);  // FMT is a constant here: the switch folds away
-}
 
-// Per-workgroup addressing (fused path requires S == 1, so compact sample n of
-// this block is input frame f0 + n, f0 = blk*Bc - Oc; frames < 0 are history).
+// Per-channel-block input addressing (fused path requires S == 1, so compact
+// sample n of this block is input frame f0 + n, f0 = blk*Bc - Oc; frames < 0
+// are history).
 struct BlockIo {
   const char *pin;    // where compact sample 0 would be in `in`   (valid for n >= n_hist)
   const char *phist;  // where compact sample 0 is in the history  (valid for n <  n_hist)
@@ -154,13 +168,59 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
 template <int LOG2K>
 struct FusedCfg {
   static constexpr int K = 1 << LOG2K;
-  static constexpr int J = K / 16;       // radix-16 butterflies per pass
+  static constexpr int J = K / 16;       // sixteen-word LDS blocks / radix-16 butterflies per pass
   static constexpr int T = K / 32;       // threads per workgroup
   static constexpr int R0 = 1 << (LOG2K % 4);
   static constexpr int LOG2R0 = LOG2K % 4;
   static constexpr int N16 = LOG2K / 4;  // radix-16 passes
+  // radix of the pass before the last one: its digit is the low digit of the block index
+  static constexpr int RL = (N16 >= 2) ? 16 : R0;
   static constexpr int LDS_BYTES = K * 8;
   static_assert(LOG2K >= 5 && LOG2K <= 14, "fused kernel covers K = 32 .. 16384");
+  // LDS block of the thread's first set in the pairing passes: the tau-th block
+  // whose low digit is < RL/2 (exactly the sets S_a with a < J/2)
+  static MI_HD constexpr int block_a(int tau) { return (tau / (RL / 2)) * RL + (tau % (RL / 2)); }
+};
+
+// LDS word indices of the R words {base + t*S} of butterfly q in a pass with
+// stride S (sub-transform length L = S*R): base = (q / S) * L + q % S.
+// The four strides that occur (K/R0 = 16^N16, 256, 16, 1) each get the cheapest
+// closed form of lds_swz(base + t*S).
+template <int R, int S>
+struct Bfly {
+  int p;  // precomputed per butterfly
+  int w;  // S == 16 only
+  MI_DEVICE explicit Bfly(int q) {
+    if constexpr (S == 1) {
+      p = lds_swz(16 * q);
+      w = 0;
+    } else if constexpr (S == 16) {
+      const int a = q >> 4, r = q & 15;
+      p = a * (16 * R);
+      // the swizzle masks only depend on a (bits 8, 9 of the word index) and t
+      w = (r ^ ((a & 1) << 3)) | (((a ^ (a >> 1)) & 1) << 4);
+      if (R < 16) {
+        w = r;  // R < 16 only happens for the first pass (a == 0)
+      }
+    } else {
+      const int base = (q / S) * (S * R) + (q % S);
+      p = lds_swz(base);
+      w = 0;
+    }
+  }
+  MI_DEVICE int at(int t) const {
+    if constexpr (S == 1) {
+      return p ^ t;
+    } else if constexpr (S == 16) {
+      return p + ((17 * t) ^ w);
+    } else if constexpr (S == 256) {
+      // bits 8, 9 of the word index are t's low bits: they flip bits 3 and 4
+      return (p ^ (((t & 1) << 3) | (((t ^ (t >> 1)) & 1) << 4))) + t * S;
+    } else {
+      static_assert(S % 1024 == 0, "unexpected pass stride");
+      return p + t * S;
+    }
+  }
 };
 
 template <int LOG2K>
@@ -168,69 +228,45 @@ struct FusedKernel {
   using Cfg = FusedCfg<LOG2K>;
   static constexpr int K = Cfg::K, J = Cfg::J, T = Cfg::T, R0 = Cfg::R0, N16 = Cfg::N16;
   static constexpr int LOG2R0 = Cfg::LOG2R0;
+  static constexpr int S0 = K / R0;  // stride of the radix-R0 pass (= 16^N16)
 
-  // ---- LDS access for one radix-R butterfly -------------------------------
-  // The swizzle only permutes within aligned groups of 16, so when the element
-  // stride is a multiple of 256 it is the same for every element.
-  template <int R>
-  static MI_DEVICE void lds_read(const cf *lds, int j, cf *v) {
-    constexpr int stride = K / R;
-    if constexpr (stride % 256 == 0) {
-      const cf *p = lds + lds_swz(j);
-      MI_UNROLL
-      for (int t = 0; t < R; ++t) {
-        v[t] = p[t * stride];
-      }
-    } else {
-      MI_UNROLL
-      for (int t = 0; t < R; ++t) {
-        v[t] = lds[lds_swz(j + t * stride)];
-      }
+  template <int R, int S>
+  static MI_DEVICE void lds_get(const cf *lds, const Bfly<R, S> &b, cf *v) {
+    MI_UNROLL
+    for (int t = 0; t < R; ++t) {
+      v[t] = lds[b.at(t)];
     }
   }
-  template <int R, int NS>
-  static MI_DEVICE void lds_write(cf *lds, int j, const cf *v) {
-    const int k = j & (NS - 1);
-    const int base = (j - k) * R + k;
-    if constexpr (NS % 256 == 0) {
-      cf *p = lds + lds_swz(base);
-      MI_UNROLL
-      for (int u = 0; u < R; ++u) {
-        p[u * NS] = v[out_pos<R>(u)];
-      }
-    } else {
-      MI_UNROLL
-      for (int u = 0; u < R; ++u) {
-        lds[lds_swz(base + u * NS)] = v[out_pos<R>(u)];
-      }
+  // natural order in v
+  template <int R, int S>
+  static MI_DEVICE void lds_put(cf *lds, const Bfly<R, S> &b, const cf *v) {
+    MI_UNROLL
+    for (int t = 0; t < R; ++t) {
+      lds[b.at(t)] = v[t];
     }
   }
-  // Twiddle loads are issued at the top of a pass, ahead of the LDS reads and the
-  // barrier, so their L2 round trip overlaps those instead of following them.
-  template <int NS, int LOG2NSR>
-  static MI_DEVICE cf load_tw(const cf *tw, int j) {
-    if constexpr (NS > 1) {
-      return tw[tw_offset(LOG2NSR) + (j & (NS - 1))];
-    } else {
-      return mk(1.0f, 0.0f);
+  // v holds dftR output (element u at v[out_pos<R>(u)])
+  template <int R, int S>
+  static MI_DEVICE void lds_put_dft(cf *lds, const Bfly<R, S> &b, const cf *v) {
+    MI_UNROLL
+    for (int u = 0; u < R; ++u) {
+      lds[b.at(u)] = v[out_pos<R>(u)];
     }
   }
-  template <int DIR, int R, int NS>
-  static MI_DEVICE void butterfly(cf *v, cf w) {
-    if constexpr (NS > 1) {
-      apply_twiddles<DIR, R>(v, w);
-    }
-    dftR<DIR, R>(v);
+
+  template <int LOG2L>
+  static MI_DEVICE cf load_tw(const cf *tw, int r) {
+    return tw[tw_offset(LOG2L) + r];
   }
 
   // ---- global load of one radix-R butterfly's inputs (forward pass 0) -----
   // kHist = false: the whole block lies in `in` (true for all but the first
   // blocks of a call), one uniform base + 32-bit offsets.
   template <int FMT, int R, bool kHist>
-  static MI_DEVICE void global_read(const BlockIo &b, int j, cf *v) {
+  static MI_DEVICE void global_read(const BlockIo &b, int q, cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
-      const int n = 2 * (j + t * (K / R));
+      const int n = 2 * (q + t * (K / R));
       const unsigned o0 = static_cast<unsigned>(n) * static_cast<unsigned>(b.in_step);
       const unsigned o1 = o0 + static_cast<unsigned>(b.in_step);
       if constexpr (kHist) {
@@ -245,13 +281,12 @@ struct FusedKernel {
   // ---- store of one radix-R butterfly's outputs (inverse last pass) ---------
   // overlap-discard (:566-569): compact samples n < Oc are dropped; the kept
   // ones go, still fp32 and phase-planar, to this workgroup's staging plane
-  // (plane[i] = y_p[Oc + i]) with lane-contiguous 8-byte stores. The epilogue
-  // turns the planes into interleaved PCM frames.
+  // (plane[i] = y_p[Oc + i]) with lane-contiguous 8-byte stores.
   template <int R, bool kEvenOc>
-  static MI_DEVICE void plane_write(float *plane, int Oc, int j, const cf *v) {
+  static MI_DEVICE void plane_write(float *plane, int Oc, int q, const cf *v) {
     MI_UNROLL
     for (int u = 0; u < R; ++u) {
-      const int n = 2 * (j + u * (K / R));
+      const int n = 2 * (q + u * (K / R));
       const cf y = v[out_pos<R>(u)];
       if constexpr (kEvenOc) {
         if (n >= Oc) {
@@ -268,124 +303,186 @@ struct FusedKernel {
     }
   }
 
-  // ---- forward pass 0 when it is a radix-R0 pass (R0 > 1) -------------------
+  // ================= forward (decimation in frequency) ======================
+  // pass 0 from HBM: y_u = DFT_R(x)_u * W_K^(u*q), written to q + u*K/R
   template <int FMT, bool kHist>
-  static MI_DEVICE void fwd_r0_impl(const BlockIo &b, cf *lds, int tid) {
-    MI_UNROLL
-    for (int i = 0; i < 32 / R0; ++i) {
-      const int j = tid + i * T;
-      cf v[R0];
-      global_read<FMT, R0, kHist>(b, j, v);
-      dftR<-1, R0>(v);
-      lds_write<R0, 1>(lds, j, v);
+  static MI_DEVICE void fwd_first(const BlockIo &b, cf *lds, const cf *tw, int tid) {
+    // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all butterflies
+    const cf w0 = load_tw<LOG2K>(tw, tid);
+    if constexpr (R0 > 1) {
+      MI_UNROLL
+      for (int i = 0; i < 32 / R0; ++i) {
+        const int q = tid + i * T;
+        cf v[R0];
+        global_read<FMT, R0, kHist>(b, q, v);
+        dftR<-1, R0>(v);
+        apply_twiddles_out<-1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
+        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), v);
+      }
+    } else {
+      cf A[16], B[16];
+      global_read<FMT, 16, kHist>(b, tid, A);
+      global_read<FMT, 16, kHist>(b, tid + T, B);
+      dft16<-1>(A);
+      apply_twiddles_out<-1, 16>(A, w0);
+      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      MI_SCHED_FENCE();
+      dft16<-1>(B);
+      apply_twiddles_out<-1, 16>(B, cmul(w0, w32(1)));
+      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
     }
   }
   template <int FMT>
-  static MI_DEVICE void fwd_r0(const BlockIo &b, cf *lds, int tid) {
+  static MI_DEVICE void fwd_first_fmt(const BlockIo &b, cf *lds, const cf *tw, int tid) {
     if (b.n_hist == 0) {
-      fwd_r0_impl<FMT, false>(b, lds, tid);
+      fwd_first<FMT, false>(b, lds, tw, tid);
     } else {
-      fwd_r0_impl<FMT, true>(b, lds, tid);
+      fwd_first<FMT, true>(b, lds, tw, tid);
     }
   }
-  // ---- forward pass 0 when it is a radix-16 pass (R0 == 1, N16 >= 2) --------
-  template <int FMT>
-  static MI_DEVICE void fwd16_from_global(const BlockIo &b, cf *lds, int tid, cf *A, cf *B) {
-    if (b.n_hist == 0) {
-      global_read<FMT, 16, false>(b, tid, A);
-      global_read<FMT, 16, false>(b, tid + T, B);
-    } else {
-      global_read<FMT, 16, true>(b, tid, A);
-      global_read<FMT, 16, true>(b, tid + T, B);
-    }
+
+  // middle radix-16 pass with stride S (16 or 256), in place
+  template <int S>
+  static MI_DEVICE void fwd_mid(cf *lds, const cf *tw, int tid) {
+    constexpr int LOG2L = (S == 16) ? 8 : 12;
+    const int qA = tid, qB = tid + T;
+    const cf wA = load_tw<LOG2L>(tw, qA & (S - 1));
+    const cf wB = (T % S == 0) ? wA : load_tw<LOG2L>(tw, qB & (S - 1));
+    const Bfly<16, S> bA(qA), bB(qB);
+    cf A[16], B[16];
+    lds_get<16, S>(lds, bA, A);
+    lds_get<16, S>(lds, bB, B);
     dft16<-1>(A);
-    lds_write<16, 1>(lds, tid, A);
+    apply_twiddles_out<-1, 16>(A, wA);
+    lds_put_dft<16, S>(lds, bA, A);
+    MI_SCHED_FENCE();
     dft16<-1>(B);
-    lds_write<16, 1>(lds, tid + T, B);
+    apply_twiddles_out<-1, 16>(B, wB);
+    lds_put_dft<16, S>(lds, bB, B);
+  }
+  // last pass (stride 1, no twiddles): the thread's two sets stay in registers,
+  // A[out_pos<16>(t)] = Z[a + t*J], B[out_pos<16>(t)] = Z[(J - a) + t*J]
+  static MI_DEVICE void fwd_last(const cf *lds, int blkA, int blkB, cf *A, cf *B) {
+    lds_get<16, 1>(lds, Bfly<16, 1>(blkA), A);
+    lds_get<16, 1>(lds, Bfly<16, 1>(blkB), B);
+    dft16<-1>(A);
+    MI_SCHED_FENCE();
+    dft16<-1>(B);
   }
 
-  // forward radix-16 pass P16 reading LDS (every pass except a global pass 0)
-  template <int P16>
-  static MI_DEVICE void fwd16(cf *lds, const cf *tw, int tid, cf *A, cf *B) {
-    constexpr int NS = R0 * (1 << (4 * P16));
-    constexpr int LOG2NSR = LOG2R0 + 4 * P16 + 4;
-    constexpr bool kLast = (P16 == N16 - 1);
-    const int jA = tid;
-    const int jB = kLast ? (tid == 0 ? T : J - tid) : tid + T;
-    const cf wA = load_tw<NS, LOG2NSR>(tw, jA);
-    // jB = jA + T indexes the same entry whenever the table period NS divides T
-    const cf wB = (!kLast && T % NS == 0) ? wA : load_tw<NS, LOG2NSR>(tw, jB);
-    lds_read<16>(lds, jA, A);
-    lds_read<16>(lds, jB, B);
-    MI_SYNC();  // every read of this pass done before anyone overwrites
-    butterfly<-1, 16, NS>(A, wA);
-    if constexpr (!kLast) {
-      lds_write<16, NS>(lds, jA, A);
-    }
+  // ================= inverse (decimation in time) ===========================
+  // first pass (stride 1): inputs in A/B (natural order), results into the
+  // thread's own two LDS blocks
+  static MI_DEVICE void inv_first(cf *lds, int blkA, int blkB, cf *A, cf *B) {
+    dft16<+1>(A);
+    lds_put_dft<16, 1>(lds, Bfly<16, 1>(blkA), A);
     MI_SCHED_FENCE();
-    butterfly<-1, 16, NS>(B, wB);
-    if constexpr (!kLast) {
-      lds_write<16, NS>(lds, jB, B);
-      MI_SYNC();
+    dft16<+1>(B);
+    lds_put_dft<16, 1>(lds, Bfly<16, 1>(blkB), B);
+  }
+  template <int S>
+  static MI_DEVICE void inv_mid(cf *lds, const cf *tw, int tid) {
+    constexpr int LOG2L = (S == 16) ? 8 : 12;
+    const int qA = tid, qB = tid + T;
+    const cf wA = load_tw<LOG2L>(tw, qA & (S - 1));
+    const cf wB = (T % S == 0) ? wA : load_tw<LOG2L>(tw, qB & (S - 1));
+    const Bfly<16, S> bA(qA), bB(qB);
+    cf A[16], B[16];
+    lds_get<16, S>(lds, bA, A);
+    lds_get<16, S>(lds, bB, B);
+    apply_twiddles<+1, 16>(A, wA);
+    dft16<+1>(A);
+    lds_put_dft<16, S>(lds, bA, A);
+    MI_SCHED_FENCE();
+    apply_twiddles<+1, 16>(B, wB);
+    dft16<+1>(B);
+    lds_put_dft<16, S>(lds, bB, B);
+  }
+  // last pass: stride K/R, natural-order results -> staging plane
+  template <bool kEvenOc>
+  static MI_DEVICE void inv_last(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
+    const cf w0 = load_tw<LOG2K>(tw, tid);
+    if constexpr (R0 > 1) {
+      MI_UNROLL
+      for (int i = 0; i < 32 / R0; ++i) {
+        const int q = tid + i * T;
+        cf v[R0];
+        lds_get<R0, S0>(lds, Bfly<R0, S0>(q), v);
+        apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
+        dftR<+1, R0>(v);
+        plane_write<R0, kEvenOc>(plane, Oc, q, v);
+        if ((i & 3) == 3) {
+          MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
+        }
+      }
+    } else {
+      cf A[16], B[16];
+      lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
+      apply_twiddles<+1, 16>(A, w0);
+      dft16<+1>(A);
+      plane_write<16, kEvenOc>(plane, Oc, tid, A);
+      MI_SCHED_FENCE();
+      apply_twiddles<+1, 16>(B, cmul(w0, w32(1)));
+      dft16<+1>(B);
+      plane_write<16, kEvenOc>(plane, Oc, tid + T, B);
     }
   }
 
-  // inverse radix-16 pass P16 that ends in LDS; pass 0 takes its inputs from A/B
-  template <int P16>
-  static MI_DEVICE void inv16(cf *lds, const cf *tw, int tid, cf *A, cf *B) {
-    constexpr int NS = 1 << (4 * P16);
-    constexpr int LOG2NSR = 4 * P16 + 4;
-    constexpr bool kFirst = (P16 == 0);
-    const int jA = tid;
-    const int jB = kFirst ? (tid == 0 ? T : J - tid) : tid + T;
-    const cf wA = load_tw<NS, LOG2NSR>(tw, jA);
-    const cf wB = (T % NS == 0) ? wA : load_tw<NS, LOG2NSR>(tw, jB);
-    if constexpr (!kFirst) {
-      lds_read<16>(lds, jA, A);
-      lds_read<16>(lds, jB, B);
-      MI_SYNC();
-    }
-    butterfly<+1, 16, NS>(A, wA);
-    lds_write<16, NS>(lds, jA, A);
-    MI_SCHED_FENCE();
-    butterfly<+1, 16, NS>(B, wB);
-    lds_write<16, NS>(lds, jB, B);
-    MI_SYNC();
-  }
-  // inverse last pass when it is a radix-16 pass (R0 == 1): LDS -> staging plane
-  template <bool kEvenOc>
-  static MI_DEVICE void inv16_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid, cf *A, cf *B) {
-    constexpr int P16 = N16 - 1;
-    constexpr int NS = 1 << (4 * P16);
-    const cf wA = load_tw<NS, 4 * P16 + 4>(tw, tid);
-    const cf wB = (T % NS == 0) ? wA : load_tw<NS, 4 * P16 + 4>(tw, tid + T);
-    lds_read<16>(lds, tid, A);
-    lds_read<16>(lds, tid + T, B);
-    butterfly<+1, 16, NS>(A, wA);
-    plane_write<16, kEvenOc>(plane, Oc, tid, A);
-    MI_SCHED_FENCE();
-    butterfly<+1, 16, NS>(B, wB);
-    plane_write<16, kEvenOc>(plane, Oc, tid + T, B);
-  }
-  // inverse last pass when it is the radix-R0 pass: LDS -> staging plane
-  template <bool kEvenOc>
-  static MI_DEVICE void inv_r0_to_plane(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
-    // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all 32/R0 butterflies
-    const cf w0 = load_tw<K / R0, LOG2K>(tw, tid);
-    MI_UNROLL
-    for (int i = 0; i < 32 / R0; ++i) {
-      const int j = tid + i * T;
-      cf v[R0];
-      lds_read<R0>(lds, j, v);
-      butterfly<+1, R0, K / R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
-      plane_write<R0, kEvenOc>(plane, Oc, j, v);
-      if ((i & 3) == 3) {
-        MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
+  // ================= spectral stage ==========================================
+  // kSelf = thread 0 (self-mirrored sets). On entry Xa/Xb hold the split
+  // spectrum, on exit A/B hold the inputs of the first inverse pass in natural
+  // order (element t of the thread's two blocks).
+  template <bool kSelf>
+  static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wb, const f4 *MI_RESTRICT gt,
+                                     const f4 *MI_RESTRICT g0, cf *A, cf *B) {
+    if constexpr (!kSelf) {
+      // pair t: k = a + t*J  <->  K-k = (J-a) + (15-t)*J
+      const f4 *pg = gt + tid;
+      MI_UNROLL
+      for (int t = 0; t < 16; ++t) {
+        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), pg[t * T], A[t], B[15 - t]);
+      }
+    } else {
+      // set S_0: k = t*J <-> (16-t)*J, t = 0..8 (t = 0 pairs DC with Nyquist
+      // through gc = conj Gs[K]; t = 8 is its own mirror)
+      MI_UNROLL
+      for (int t = 0; t <= 8; ++t) {
+        cf zk, zkm;
+        pair_phase(Xa[t], Xb[t], w32(t), g0[t], zk, zkm);
+        A[t] = zk;
+        if (t >= 1 && t <= 7) {
+          A[16 - t] = zkm;
+        }
+      }
+      // set S_{J/2}: k = J/2 + t*J <-> J/2 + (15-t)*J, t = 0..7
+      MI_UNROLL
+      for (int t = 0; t < 8; ++t) {
+        pair_phase(Xa[9 + t], Xb[9 + t], cmul(Wb, w32(t)), g0[9 + t], B[t], B[15 - t]);
       }
     }
   }
 
-  // ---- epilogue: staging planes -> interleaved PCM frames ---------------------
+  template <bool kSelf>
+  static MI_DEVICE void split_spectrum(const cf *A, const cf *B, cf Wa, cf Wb, cf *Xa, cf *Xb) {
+    if constexpr (!kSelf) {
+      MI_UNROLL
+      for (int t = 0; t < 16; ++t) {
+        pair_split(A[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wa, w32(t)), Xa[t], Xb[t]);
+      }
+    } else {
+      MI_UNROLL
+      for (int t = 0; t <= 8; ++t) {
+        pair_split(A[out_pos<16>(t)], A[out_pos<16>((16 - t) & 15)], w32(t), Xa[t], Xb[t]);
+      }
+      MI_UNROLL
+      for (int t = 0; t < 8; ++t) {
+        pair_split(B[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wb, w32(t)), Xa[9 + t], Xb[9 + t]);
+      }
+    }
+  }
+
+  // ================= epilogue: staging planes -> interleaved PCM frames ======
   // scr[(cc*P + p)*Bc + i] = y_p[Oc + i] of channel c0+cc; output frame
   // blk*B + i*P + p, channel c0+cc (reference: interleave + ConvertFloatToPcm,
   // alsa_streamer_main.cpp:327-329,550-552; alsa_common.cpp:87-127).
@@ -423,10 +520,11 @@ struct FusedKernel {
           MI_UNROLL
           for (int e = 0; e < VPT; e += 4) {
             if constexpr (FMT == kF32) {
-              struct alignas(16) F4 { float a, b, c, d; };
-              *reinterpret_cast<F4 *>(dst + 4 * e) = F4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
+              *reinterpret_cast<f4 *>(dst + 4 * e) = f4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
             } else {
-              struct alignas(16) I4 { int32_t a, b, c, d; };
+              struct alignas(16) I4 {
+                int32_t a, b, c, d;
+              };
               I4 w;
               w.a = static_cast<int32_t>(pcm_clamp(v[d][e], 0.9999999f) * 2147483648.0f);
               w.b = static_cast<int32_t>(pcm_clamp(v[d][e + 1], 0.9999999f) * 2147483648.0f);
@@ -480,149 +578,85 @@ struct FusedKernel {
     }
   }
 
-  // spectral stage for one phase. kSelf = thread 0 (self-mirrored sets).
-  // On entry Xa/Xb hold the split spectrum, on exit A/B hold the inputs of
-  // inverse pass 0 in natural order (element t of butterflies jA / jB).
-  template <bool kSelf>
-  static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wb, const cf *MI_RESTRICT gs,
-                                     const cf *MI_RESTRICT gc, cf *A, cf *B) {
-    if constexpr (!kSelf) {
-      // pair t: k = tid + t*J  <->  K-k = (J-tid) + (15-t)*J
-      const cf *ps = gs + tid, *pc = gc + tid;
-      MI_UNROLL
-      for (int t = 0; t < 16; ++t) {
-        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), ps[t * J], pc[t * J], A[t], B[15 - t]);
-      }
-    } else {
-      // set S_0: k = t*J <-> (16-t)*J, t = 0..8 (t = 0 pairs DC with Nyquist
-      // through gc[0] = conj Gs[K]; t = 8 is its own mirror)
-      MI_UNROLL
-      for (int t = 0; t <= 8; ++t) {
-        cf zk, zkm;
-        pair_phase(Xa[t], Xb[t], w32(t), gs[t * J], gc[t * J], zk, zkm);
-        A[t] = zk;
-        if (t >= 1 && t <= 7) {
-          A[16 - t] = zkm;
-        }
-      }
-      // set S_T: k = T + t*J <-> T + (15-t)*J, t = 0..7
-      MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        const int k = T + t * J;
-        pair_phase(Xa[9 + t], Xb[9 + t], cmul(Wb, w32(t)), gs[k], gc[k], B[t], B[15 - t]);
-      }
-    }
-  }
-
-  template <bool kSelf>
-  static MI_DEVICE void split_spectrum(int tid, const cf *A, const cf *B, cf Wa, cf Wb, cf *Xa, cf *Xb) {
-    // A[out_pos<16>(t)] = Z[jA + t*J], B likewise for jB
-    if constexpr (!kSelf) {
-      MI_UNROLL
-      for (int t = 0; t < 16; ++t) {
-        pair_split(A[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wa, w32(t)), Xa[t], Xb[t]);
-      }
-    } else {
-      MI_UNROLL
-      for (int t = 0; t <= 8; ++t) {
-        pair_split(A[out_pos<16>(t)], A[out_pos<16>((16 - t) & 15)], w32(t), Xa[t], Xb[t]);
-      }
-      MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        pair_split(B[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wb, w32(t)), Xa[9 + t], Xb[9 + t]);
-      }
-    }
-  }
-
   // One channel-block: forward FFT, split, then per phase multiply + inverse FFT
   // into this channel's staging planes (scr_c = [P][Bc] floats).
   static MI_DEVICE void channel_block(const Geometry &g, const IoDesc &io, const BlockIo &b, float *scr_c,
-                                      const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm, const cf *MI_RESTRICT Gs,
-                                      const cf *MI_RESTRICT Gc, cf *lds, int tid) {
-    cf A[16], B[16];
-
+                                      const FusedTables &ft, cf *lds, int tid) {
     // ------------------------------ forward ------------------------------
-    if constexpr (R0 > 1) {
-      switch (io.in_fmt) {
-        case kS32: fwd_r0<kS32>(b, lds, tid); break;
-        case kF32: fwd_r0<kF32>(b, lds, tid); break;
-        case kS16: fwd_r0<kS16>(b, lds, tid); break;
-        default: fwd_r0<kS24_3LE>(b, lds, tid); break;
-      }
-      MI_SYNC();
-      fwd16<0>(lds, tw, tid, A, B);
-    } else {
-      switch (io.in_fmt) {
-        case kS32: fwd16_from_global<kS32>(b, lds, tid, A, B); break;
-        case kF32: fwd16_from_global<kF32>(b, lds, tid, A, B); break;
-        case kS16: fwd16_from_global<kS16>(b, lds, tid, A, B); break;
-        default: fwd16_from_global<kS24_3LE>(b, lds, tid, A, B); break;
-      }
+    switch (io.in_fmt) {
+      case kS32: fwd_first_fmt<kS32>(b, lds, ft.tw, tid); break;
+      case kF32: fwd_first_fmt<kF32>(b, lds, ft.tw, tid); break;
+      case kS16: fwd_first_fmt<kS16>(b, lds, ft.tw, tid); break;
+      default: fwd_first_fmt<kS24_3LE>(b, lds, ft.tw, tid); break;
+    }
+    MI_SYNC();
+    // radix-16 passes with strides 256 and 16 exist when K/R0 >= 4096 resp. >= 256
+    // (when R0 == 1 the first pass already was the stride-K/16 radix-16 pass)
+    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    if constexpr (kFirstMidStride >= 256) {
+      fwd_mid<256>(lds, ft.tw, tid);
       MI_SYNC();
     }
-    if constexpr (N16 >= 2) {
-      fwd16<1>(lds, tw, tid, A, B);
+    if constexpr (kFirstMidStride >= 16) {
+      fwd_mid<16>(lds, ft.tw, tid);
+      MI_SYNC();
     }
-    if constexpr (N16 >= 3) {
-      fwd16<2>(lds, tw, tid, A, B);
-    }
+    const int blkA = Cfg::block_a(tid);
+    const int blkB = ft.blockB[tid];
+    cf A[16], B[16];
+    fwd_last(lds, blkA, blkB, A, B);
+    // no barrier: the next LDS access is this thread writing its own two blocks
 
     // ------------------------- split (once per block) --------------------
     cf Xa[17], Xb[17];
-    const cf Wa = Wm[tid];  // W_M^tid ; thread 0: W_M^0 = 1 (unused)
-    const cf Wb = Wm[T];    // W_M^T   ; used by thread 0 only
+    const cf Wa = ft.WmT[tid];
+    const cf Wb = ft.Wb;
     if (tid == 0) {
-      split_spectrum<true>(tid, A, B, Wa, Wb, Xa, Xb);
+      split_spectrum<true>(A, B, Wa, Wb, Xa, Xb);
     } else {
-      split_spectrum<false>(tid, A, B, Wa, Wb, Xa, Xb);
+      split_spectrum<false>(A, B, Wa, Wb, Xa, Xb);
     }
 
     // --------------------------- per output phase ------------------------
     const bool evenOc = (b.Oc & 1) == 0;
     for (int p = 0; p < g.P; ++p) {
-      const cf *gs = Gs + static_cast<long long>(p) * K;
-      const cf *gc = Gc + static_cast<long long>(p) * K;
+      const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
+      const f4 *g0 = ft.G0 + p * 17;
       float *plane = scr_c + static_cast<long long>(p) * g.Bc;
       int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
       MI_OPAQUE_VGPR(tl);
       if (tid == 0) {
-        phase_inputs<true>(tl, Xa, Xb, Wa, Wb, gs, gc, A, B);
+        phase_inputs<true>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       } else {
-        phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gs, gc, A, B);
+        phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       }
-      constexpr int kLdsInv = (R0 > 1) ? N16 : N16 - 1;  // inverse radix-16 passes that end in LDS
-      if constexpr (kLdsInv >= 1) {
-        inv16<0>(lds, tw, tl, A, B);
-      }
-      if constexpr (kLdsInv >= 2) {
+      int ba = blkA, bb = blkB;
+      MI_OPAQUE_VGPR(ba);
+      MI_OPAQUE_VGPR(bb);
+      inv_first(lds, ba, bb, A, B);
+      MI_SYNC();
+      if constexpr (kFirstMidStride >= 16) {
         MI_OPAQUE_VGPR(tl);
-        inv16<1>(lds, tw, tl, A, B);
+        inv_mid<16>(lds, ft.tw, tl);
+        MI_SYNC();
       }
-      if constexpr (kLdsInv >= 3) {
+      if constexpr (kFirstMidStride >= 256) {
         MI_OPAQUE_VGPR(tl);
-        inv16<2>(lds, tw, tl, A, B);
+        inv_mid<256>(lds, ft.tw, tl);
+        MI_SYNC();
       }
       MI_OPAQUE_VGPR(tl);
-      if constexpr (R0 > 1) {
-        if (evenOc) {
-          inv_r0_to_plane<true>(plane, b.Oc, lds, tw, tl);
-        } else {
-          inv_r0_to_plane<false>(plane, b.Oc, lds, tw, tl);
-        }
+      if (evenOc) {
+        inv_last<true>(plane, b.Oc, lds, ft.tw, tl);
       } else {
-        if (evenOc) {
-          inv16_to_plane<true>(plane, b.Oc, lds, tw, tl, A, B);
-        } else {
-          inv16_to_plane<false>(plane, b.Oc, lds, tw, tl, A, B);
-        }
+        inv_last<false>(plane, b.Oc, lds, ft.tw, tl);
       }
-      MI_SYNC();  // LDS free for the next phase
+      MI_SYNC();  // every read of this phase done before the next phase's first pass writes
     }
   }
 
   // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
-  static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm,
-                            const cf *MI_RESTRICT Gs, const cf *MI_RESTRICT Gc, cf *lds) {
+  static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
     const int local = MI_BID_X;
     const int item = io.item0 + local;
@@ -636,7 +670,7 @@ struct FusedKernel {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
-      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, tw, Wm, Gs, Gc, lds, tc);
+      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc);
     }
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
@@ -645,11 +679,11 @@ struct FusedKernel {
 };
 
 template <int LOG2K>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_kernel(
-    Geometry g, IoDesc io, const cf *MI_RESTRICT tw, const cf *MI_RESTRICT Wm, const cf *MI_RESTRICT Gs,
-    const cf *MI_RESTRICT Gc) {
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_kernel(Geometry g,
+                                                                                                      IoDesc io,
+                                                                                                      FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K>::run(g, io, tw, Wm, Gs, Gc, lds);
+  FusedKernel<LOG2K>::run(g, io, ft, lds);
 }
 
 }  // namespace miups

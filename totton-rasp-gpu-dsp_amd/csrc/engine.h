@@ -38,6 +38,8 @@ class DeviceFilter {
   const cf *Gc() const { return dGc_; }
   const cf *Wm() const { return dWm_; }
   const cf *tw() const { return dtw_; }
+  bool hasFused() const { return hasFused_; }
+  FusedTables fused() const { return FusedTables{dtw_, dWmT_, dBlockB_, dGT_, dG0_, wb_}; }
 
  private:
   DeviceFilter() = default;
@@ -50,6 +52,12 @@ class DeviceFilter {
   int flags_ = 0;
   Geometry geo_{};
   cf *dGs_ = nullptr, *dGc_ = nullptr, *dWm_ = nullptr, *dtw_ = nullptr;
+  // fused-kernel layout of the same spectra (FusedTables)
+  bool hasFused_ = false;
+  cf *dWmT_ = nullptr;
+  int *dBlockB_ = nullptr;
+  f4 *dGT_ = nullptr, *dG0_ = nullptr;
+  cf wb_{1.0f, 0.0f};
 };
 
 // Evaluate an APO profile's cascade on the device: bins 0..numBins-1 (fp64).

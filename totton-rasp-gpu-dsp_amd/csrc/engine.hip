@@ -150,8 +150,7 @@ bool LaunchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, uns
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.tw(), f.Wm(),
-                     f.Gs(), f.Gc());
+  hipLaunchKernelGGL((fused_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
 }
 
@@ -207,7 +206,14 @@ void DeviceFilter::Free() {
   (void)hipFree(dGc_);
   (void)hipFree(dWm_);
   (void)hipFree(dtw_);
-  dGs_ = dGc_ = dWm_ = dtw_ = nullptr;
+  (void)hipFree(dWmT_);
+  (void)hipFree(dBlockB_);
+  (void)hipFree(dGT_);
+  (void)hipFree(dG0_);
+  dGs_ = dGc_ = dWm_ = dtw_ = dWmT_ = nullptr;
+  dBlockB_ = nullptr;
+  dGT_ = dG0_ = nullptr;
+  hasFused_ = false;
 }
 
 std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfig &config, std::vector<float> taps,
@@ -242,8 +248,19 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
   MI_HIP(hipDeviceSynchronize());
   Free();
   geo_ = t.geo;
-  return Upload(t.Gs, &dGs_, error) && Upload(t.Gc, &dGc_, error) && Upload(t.Wm, &dWm_, error) &&
-         Upload(t.tw, &dtw_, error);
+  if (!(Upload(t.Gs, &dGs_, error) && Upload(t.Gc, &dGc_, error) && Upload(t.Wm, &dWm_, error) &&
+        Upload(t.tw, &dtw_, error))) {
+    return false;
+  }
+  if (t.hasFused) {
+    if (!(Upload(t.WmT, &dWmT_, error) && Upload(t.blockB, &dBlockB_, error) && Upload(t.GT, &dGT_, error) &&
+          Upload(t.G0, &dG0_, error))) {
+      return false;
+    }
+    wb_ = t.Wb;
+    hasFused_ = true;
+  }
+  return true;
 }
 
 bool DeviceFilter::SetEq(const std::string &apoText, double fsOut, std::string *error) {
@@ -345,7 +362,7 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->inFmt_ = inFmt;
   e->outFmt_ = outFmt;
   const Geometry &g = e->filter_->geometry();
-  e->fused_ = FusedCovers(g, channels, inFmt, outFmt);
+  e->fused_ = e->filter_->hasFused() && FusedCovers(g, channels, inFmt, outFmt);
   // channel group per workgroup: the largest divisor of `channels` that is <= 8, so that a
   // group's samples of one frame are one contiguous run (whole frames when channels <= 8)
   e->cg_ = 1;

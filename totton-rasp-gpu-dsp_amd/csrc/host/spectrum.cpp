@@ -16,7 +16,83 @@ int Log2(std::size_t v) {
   return r;
 }
 
+// radices of the fused kernel's forward passes for K = 2^log2k
+std::vector<int> FusedRadices(int log2k) {
+  std::vector<int> r;
+  if (log2k % 4) {
+    r.push_back(1 << (log2k % 4));
+  }
+  for (int i = 0; i < log2k / 4; ++i) {
+    r.push_back(16);
+  }
+  return r;
+}
+
+void BuildFusedLayout(FilterTables *t) {
+  const Geometry &g = t->geo;
+  t->hasFused = false;
+  if (g.S != 1 || g.log2k < 5 || g.log2k > 14) {
+    return;
+  }
+  const int K = g.K, P = g.P, J = K / 16, T = K / 32;
+  std::vector<int> blockOfSet(J);
+  for (int b = 0; b < J; ++b) {
+    blockOfSet[FusedSetOfBlock(b, g.log2k)] = b;
+  }
+  t->WmT.assign(T, cf{1.0f, 0.0f});
+  t->blockB.assign(T, 0);
+  t->GT.assign(static_cast<std::size_t>(P) * 16 * T, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->G0.assign(static_cast<std::size_t>(P) * 17, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->Wb = t->Wm[J / 2];
+  auto pair = [&](int p, int k) {
+    const cf gs = t->Gs[static_cast<std::size_t>(p) * K + k];
+    const cf gc = t->Gc[static_cast<std::size_t>(p) * K + k];
+    return f4{gs.x, gs.y, gc.x, gc.y};
+  };
+  t->blockB[0] = blockOfSet[J / 2];
+  for (int tau = 1; tau < T; ++tau) {
+    const int a = FusedSetOfBlock(FusedBlockA(tau, g.log2k), g.log2k);  // 0 < a < J/2
+    t->WmT[tau] = t->Wm[a];
+    t->blockB[tau] = blockOfSet[J - a];
+    for (int p = 0; p < P; ++p) {
+      for (int s = 0; s < 16; ++s) {
+        t->GT[(static_cast<std::size_t>(p) * 16 + s) * T + tau] = pair(p, a + s * J);
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p) {
+    for (int s = 0; s <= 8; ++s) {
+      t->G0[static_cast<std::size_t>(p) * 17 + s] = pair(p, s * J);
+    }
+    for (int s = 0; s < 8; ++s) {
+      t->G0[static_cast<std::size_t>(p) * 17 + 9 + s] = pair(p, J / 2 + s * J);
+    }
+  }
+  t->hasFused = true;
+}
+
 }  // namespace
+
+int FusedSetOfBlock(int block, int log2k) {
+  // block digits, most significant first, are the output digits u_0, u_1, ..
+  // of the passes before the last; the set index has them least significant first
+  const std::vector<int> radices = FusedRadices(log2k);
+  int stride = (1 << log2k);
+  int set = 0, weight = 1;
+  for (std::size_t i = 0; i + 1 < radices.size(); ++i) {
+    stride /= radices[i];
+    const int digit = (block / (stride / 16)) % radices[i];
+    set += digit * weight;
+    weight *= radices[i];
+  }
+  return set;
+}
+
+int FusedBlockA(int tau, int log2k) {
+  const std::vector<int> radices = FusedRadices(log2k);
+  const int rl = radices.size() >= 2 ? radices[radices.size() - 2] : 2;
+  return (tau / (rl / 2)) * rl + (tau % (rl / 2));
+}
 
 bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage) {
   const std::size_t N = config.fftSize, B = config.blockSize;
@@ -154,6 +230,7 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
       out->tw[tw_offset(q) + k] = cf{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
     }
   }
+  BuildFusedLayout(out);
   return true;
 }
 

@@ -26,7 +26,21 @@ struct FilterTables {
   std::vector<cf> Gc;  // [P][K]  conj(G_p[K-k]) / (2M)   (index 0 holds the Nyquist bin)
   std::vector<cf> Wm;  // [K]     exp(-2 pi i k / M)
   std::vector<cf> tw;  // see tw_offset() in device/fft_radix.h
+  // The same spectra in the fused kernel's thread order (FusedTables in
+  // device/common.h); empty when the geometry is outside the fused kernel.
+  bool hasFused = false;
+  std::vector<cf> WmT;      // [T]
+  std::vector<int> blockB;  // [T]
+  std::vector<f4> GT;       // [P][16][T]
+  std::vector<f4> G0;       // [P][17]
+  cf Wb{1.0f, 0.0f};
 };
+
+// Frequency layout of the fused kernel's in-place FFT (radices R0,16,..,16,
+// decimation in frequency): after the forward transform LDS block b holds the
+// bins {SetOfBlock(b) + t*K/16}. Exposed for the layout tests.
+int FusedSetOfBlock(int block, int log2k);
+int FusedBlockA(int tau, int log2k);  // first block of thread tau in the pairing passes
 
 bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage);
 
