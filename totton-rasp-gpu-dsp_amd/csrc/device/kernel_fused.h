@@ -56,6 +56,22 @@
 #define MI_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 
+// Diagnostic build only (-DMIUPS_STAMPS, library variant under lib_ablate/): lane 0 of
+// every wave of the first 32 workgroups records s_memtime at fixed points so that
+// scripts/stamps_report.py can print where a workgroup's cycles go. The stamps land in a
+// buffer of their own; no product build contains them.
+#if defined(MIUPS_STAMPS) && !defined(MIUPS_HOST_EMU)
+__device__ unsigned long long mi_stamps[32][8][192];
+#define MI_STAMP(id)                                                                       \
+  do {                                                                                     \
+    if ((MI_TID_X & 63) == 0 && MI_BID_X < 32) {                                           \
+      mi_stamps[MI_BID_X][MI_TID_X >> 6][(id)] = __builtin_amdgcn_s_memtime();             \
+    }                                                                                      \
+  } while (0)
+#else
+#define MI_STAMP(id)
+#endif
+
 namespace miups {
 
 // LDS word (8-byte complex) index swizzle. Every pass touches, per wave
@@ -581,7 +597,10 @@ struct FusedKernel {
   // One channel-block: forward FFT, split, then per phase multiply + inverse FFT
   // into this channel's staging planes (scr_c = [P][Bc] floats).
   static MI_DEVICE void channel_block(const Geometry &g, const IoDesc &io, const BlockIo &b, float *scr_c,
-                                      const FusedTables &ft, cf *lds, int tid) {
+                                      const FusedTables &ft, cf *lds, int tid, int cc) {
+    const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
+    (void)sb;
+    MI_STAMP(sb + 0);
     // ------------------------------ forward ------------------------------
     switch (io.in_fmt) {
       case kS32: fwd_first_fmt<kS32>(b, lds, ft.tw, tid); break;
@@ -589,22 +608,29 @@ struct FusedKernel {
       case kS16: fwd_first_fmt<kS16>(b, lds, ft.tw, tid); break;
       default: fwd_first_fmt<kS24_3LE>(b, lds, ft.tw, tid); break;
     }
+    MI_STAMP(sb + 1);
     MI_SYNC();
+    MI_STAMP(sb + 2);
     // radix-16 passes with strides 256 and 16 exist when K/R0 >= 4096 resp. >= 256
     // (when R0 == 1 the first pass already was the stride-K/16 radix-16 pass)
     constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
     if constexpr (kFirstMidStride >= 256) {
       fwd_mid<256>(lds, ft.tw, tid);
+      MI_STAMP(sb + 3);
       MI_SYNC();
+      MI_STAMP(sb + 4);
     }
     if constexpr (kFirstMidStride >= 16) {
       fwd_mid<16>(lds, ft.tw, tid);
+      MI_STAMP(sb + 5);
       MI_SYNC();
+      MI_STAMP(sb + 6);
     }
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
     cf A[16], B[16];
     fwd_last(lds, blkA, blkB, A, B);
+    MI_STAMP(sb + 7);
     // no barrier: the next LDS access is this thread writing its own two blocks
 
     // ------------------------- split (once per block) --------------------
@@ -616,6 +642,7 @@ struct FusedKernel {
     } else {
       split_spectrum<false>(A, B, Wa, Wb, Xa, Xb);
     }
+    MI_STAMP(sb + 8);
 
     // --------------------------- per output phase ------------------------
     const bool evenOc = (b.Oc & 1) == 0;
@@ -630,20 +657,29 @@ struct FusedKernel {
       } else {
         phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       }
+      const int sp = sb + 9 + 10 * (p & 3);
+      (void)sp;
+      MI_STAMP(sp + 0);
       int ba = blkA, bb = blkB;
       MI_OPAQUE_VGPR(ba);
       MI_OPAQUE_VGPR(bb);
       inv_first(lds, ba, bb, A, B);
+      MI_STAMP(sp + 1);
       MI_SYNC();
+      MI_STAMP(sp + 2);
       if constexpr (kFirstMidStride >= 16) {
         MI_OPAQUE_VGPR(tl);
         inv_mid<16>(lds, ft.tw, tl);
+        MI_STAMP(sp + 3);
         MI_SYNC();
+        MI_STAMP(sp + 4);
       }
       if constexpr (kFirstMidStride >= 256) {
         MI_OPAQUE_VGPR(tl);
         inv_mid<256>(lds, ft.tw, tl);
+        MI_STAMP(sp + 5);
         MI_SYNC();
+        MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
       if (evenOc) {
@@ -651,7 +687,9 @@ struct FusedKernel {
       } else {
         inv_last<false>(plane, b.Oc, lds, ft.tw, tl);
       }
+      MI_STAMP(sp + 7);
       MI_SYNC();  // every read of this phase done before the next phase's first pass writes
+      MI_STAMP(sp + 8);
     }
   }
 
@@ -670,11 +708,13 @@ struct FusedKernel {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
-      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc);
+      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
     }
+    MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
     epilogue(g, io, s, c0, blk, scr, tid);
+    MI_STAMP(129);
   }
 };
 

@@ -665,3 +665,14 @@ double Engine::LastKernelMs() {
 }
 
 }  // namespace miups
+
+#if defined(MIUPS_STAMPS)
+// Diagnostic library variant only (see MI_STAMP in device/kernel_fused.h).
+extern "C" int mi_debug_read_stamps(unsigned long long *out, size_t count) {
+  const size_t total = sizeof(mi_stamps) / sizeof(unsigned long long);
+  if (!out || count < total) {
+    return static_cast<int>(total);
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi_stamps), sizeof(mi_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
