@@ -166,6 +166,12 @@ struct BlockIo {
   int in_step;
   int n_hist;
   int Oc;
+  // 0: one load per sample. 1: mono, 4-byte samples, 8-byte aligned -> the two
+  // samples of a complex input word are one 8-byte load. 2: stereo, 4-byte
+  // samples, 16-byte aligned -> two whole frames are one 16-byte load (lanes read
+  // consecutive 16-byte words: full cache lines) and the channel is picked from it.
+  int vec_mode;
+  int chan;
 };
 
 MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int c, int blk) {
@@ -178,6 +184,16 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
             ((g.hist_frames + f0) * io.channels + c) * ib;
   b.n_hist = f0 >= 0 ? 0 : (-f0 > g.M ? g.M : static_cast<int>(-f0));
   b.Oc = g.Oc;
+  b.chan = c;
+  b.vec_mode = 0;
+  if (b.n_hist == 0 && (io.in_fmt == kS32 || io.in_fmt == kF32)) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(b.pin);
+    if (io.channels == 1 && (a & 7) == 0) {
+      b.vec_mode = 1;
+    } else if (io.channels == 2 && ((a - 4ull * c) & 15) == 0) {
+      b.vec_mode = 2;
+    }
+  }
   return b;
 }
 
@@ -278,11 +294,36 @@ struct FusedKernel {
   // ---- global load of one radix-R butterfly's inputs (forward pass 0) -----
   // kHist = false: the whole block lies in `in` (true for all but the first
   // blocks of a call), one uniform base + 32-bit offsets.
-  template <int FMT, int R, bool kHist>
+  // MODE: BlockIo::vec_mode (1 and 2 imply !kHist and a 4-byte format)
+  template <int FMT, int R, bool kHist, int MODE>
   static MI_DEVICE void global_read(const BlockIo &b, int q, cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
       const int n = 2 * (q + t * (K / R));
+      if constexpr (MODE == 1) {
+        struct alignas(8) W2 {
+          int32_t a, b;
+        };
+        const W2 w = *reinterpret_cast<const W2 *>(b.pin + static_cast<unsigned>(n) * 4u);
+        if constexpr (FMT == kF32) {
+          v[t] = mk(__builtin_bit_cast(float, w.a), __builtin_bit_cast(float, w.b));
+        } else {
+          v[t] = mk(static_cast<float>(w.a) * (1.0f / 2147483648.0f), static_cast<float>(w.b) * (1.0f / 2147483648.0f));
+        }
+        continue;
+      } else if constexpr (MODE == 2) {
+        struct alignas(16) W4 {
+          int32_t a, b, c, d;
+        };
+        const W4 w = *reinterpret_cast<const W4 *>(b.pin - 4 * b.chan + static_cast<unsigned>(n) * 8u);
+        const int32_t lo = b.chan ? w.b : w.a, hi = b.chan ? w.d : w.c;
+        if constexpr (FMT == kF32) {
+          v[t] = mk(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+        } else {
+          v[t] = mk(static_cast<float>(lo) * (1.0f / 2147483648.0f), static_cast<float>(hi) * (1.0f / 2147483648.0f));
+        }
+        continue;
+      }
       const unsigned o0 = static_cast<unsigned>(n) * static_cast<unsigned>(b.in_step);
       const unsigned o1 = o0 + static_cast<unsigned>(b.in_step);
       if constexpr (kHist) {
@@ -321,24 +362,29 @@ struct FusedKernel {
 
   // ================= forward (decimation in frequency) ======================
   // pass 0 from HBM: y_u = DFT_R(x)_u * W_K^(u*q), written to q + u*K/R
-  template <int FMT, bool kHist>
+  template <int FMT, bool kHist, int MODE>
   static MI_DEVICE void fwd_first(const BlockIo &b, cf *lds, const cf *tw, int tid) {
     // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all butterflies
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
+      // every input load of the thread is issued before the first butterfly, so the
+      // HBM round trip is paid once, not once per butterfly
+      cf raw[32 / R0][R0];
+      MI_UNROLL
+      for (int i = 0; i < 32 / R0; ++i) {
+        global_read<FMT, R0, kHist, MODE>(b, tid + i * T, raw[i]);
+      }
       MI_UNROLL
       for (int i = 0; i < 32 / R0; ++i) {
         const int q = tid + i * T;
-        cf v[R0];
-        global_read<FMT, R0, kHist>(b, q, v);
-        dftR<-1, R0>(v);
-        apply_twiddles_out<-1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
-        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), v);
+        dftR<-1, R0>(raw[i]);
+        apply_twiddles_out<-1, R0>(raw[i], i == 0 ? w0 : cmul(w0, w32(i)));
+        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), raw[i]);
       }
     } else {
       cf A[16], B[16];
-      global_read<FMT, 16, kHist>(b, tid, A);
-      global_read<FMT, 16, kHist>(b, tid + T, B);
+      global_read<FMT, 16, kHist, MODE>(b, tid, A);
+      global_read<FMT, 16, kHist, MODE>(b, tid + T, B);
       dft16<-1>(A);
       apply_twiddles_out<-1, 16>(A, w0);
       lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
@@ -350,10 +396,20 @@ struct FusedKernel {
   }
   template <int FMT>
   static MI_DEVICE void fwd_first_fmt(const BlockIo &b, cf *lds, const cf *tw, int tid) {
+    if constexpr (FMT == kS32 || FMT == kF32) {
+      if (b.vec_mode == 2) {
+        fwd_first<FMT, false, 2>(b, lds, tw, tid);
+        return;
+      }
+      if (b.vec_mode == 1) {
+        fwd_first<FMT, false, 1>(b, lds, tw, tid);
+        return;
+      }
+    }
     if (b.n_hist == 0) {
-      fwd_first<FMT, false>(b, lds, tw, tid);
+      fwd_first<FMT, false, 0>(b, lds, tw, tid);
     } else {
-      fwd_first<FMT, true>(b, lds, tw, tid);
+      fwd_first<FMT, true, 0>(b, lds, tw, tid);
     }
   }
 
@@ -513,7 +569,7 @@ struct FusedKernel {
     const int units = g.Bc * qn;
     // kDepth units per step so that kDepth*VPT plane loads are in flight per lane
     // (the planes come back from L2 / Infinity Cache, ~1-2 us round trip)
-    constexpr int kDepth = VPT >= 16 ? 2 : 4;
+    constexpr int kDepth = VPT >= 16 ? 4 : 8;
     for (int base = tid; base < units; base += T * kDepth) {
       float v[kDepth][VPT];
       MI_UNROLL
