@@ -752,13 +752,20 @@ struct FusedKernel {
   // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
   static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
-    const int local = MI_BID_X;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+    // hardware ids b and b+8 share an L2. Map them to CONSECUTIVE work items:
+    // consecutive blocks of one stream overlap in (taps-1)/L input frames, and an
+    // XCD then finds that history (and its neighbours' new input) in its own L2.
+    // Placement only affects speed; any mapping is a bijection onto the items.
+    const int nwg = MI_GDIM_X, hw = MI_BID_X;
+    const int xq = nwg / 8, xr = nwg % 8, xk = hw % 8;
+    const int local = xk * xq + (xk < xr ? xk : xr) + hw / 8;
+    // item = (stream*groups + group) * blocks + block   (block fastest)
     const int item = io.item0 + local;
-    const int per_blk = io.streams * io.groups;
-    const int blk = item / per_blk;
-    const int rem = item - blk * per_blk;
-    const int s = rem / io.groups;
-    const int c0 = (rem - s * io.groups) * io.cg;
+    const int sg = item / io.blocks;
+    const int blk = item - sg * io.blocks;
+    const int s = sg / io.groups;
+    const int c0 = (sg - s * io.groups) * io.cg;
     float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.B;
     for (int cc = 0; cc < io.cg; ++cc) {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
