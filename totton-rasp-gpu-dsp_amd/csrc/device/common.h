@@ -98,9 +98,8 @@ struct FusedTables {
   const cf *tw;        // Stockham/Cooley-Tukey pass twiddles, see tw_offset()
   const cf *WmT;       // [T]            W_M^a                     (a = low index of the thread's first set)
   const int *blockB;   // [T]            LDS block that holds the thread's second set after the forward FFT
-  const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau); column 0 holds
-                       //                thread 0's pairs: k = t*J (t = 0..8), then k = J/2 + (t-9)*J (t = 9..15)
-  const f4 *G0;        // [P]            thread 0's 17th pair: k = J/2 + 7*J
+  const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau)
+  const f4 *G0;        // [P][17]        thread 0: k = t*J (t = 0..8) then k = J/2 + t*J (t = 0..7)
   cf Wb;               // W_M^(J/2)
 };
 

@@ -505,25 +505,15 @@ struct FusedKernel {
   // kSelf = thread 0 (self-mirrored sets). On entry Xa/Xb hold the split
   // spectrum, on exit A/B hold the inputs of the first inverse pass in natural
   // order (element t of the thread's two blocks).
-  // The thread's 16 spectrum pairs of one phase (thread 0: 17, the last one in gx).
-  // Loaded ahead of the previous phase's plane stores: vector-memory operations of
-  // a wave retire in issue order, so a load issued behind stores waits for them.
-  static MI_DEVICE void load_g(const f4 *MI_RESTRICT gt, const f4 *MI_RESTRICT g0, int p, int tid, f4 *gv, f4 &gx) {
-    const f4 *pg = gt + static_cast<long long>(p) * 16 * T + tid;
-    MI_UNROLL
-    for (int t = 0; t < 16; ++t) {
-      gv[t] = pg[t * T];
-    }
-    gx = g0[p];
-  }
-
   template <bool kSelf>
-  static MI_DEVICE void phase_inputs(const cf *Xa, const cf *Xb, cf Wa, cf Wb, const f4 *gv, f4 gx, cf *A, cf *B) {
+  static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wb, const f4 *MI_RESTRICT gt,
+                                     const f4 *MI_RESTRICT g0, cf *A, cf *B) {
     if constexpr (!kSelf) {
       // pair t: k = a + t*J  <->  K-k = (J-a) + (15-t)*J
+      const f4 *pg = gt + tid;
       MI_UNROLL
       for (int t = 0; t < 16; ++t) {
-        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), gv[t], A[t], B[15 - t]);
+        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), pg[t * T], A[t], B[15 - t]);
       }
     } else {
       // set S_0: k = t*J <-> (16-t)*J, t = 0..8 (t = 0 pairs DC with Nyquist
@@ -531,7 +521,7 @@ struct FusedKernel {
       MI_UNROLL
       for (int t = 0; t <= 8; ++t) {
         cf zk, zkm;
-        pair_phase(Xa[t], Xb[t], w32(t), gv[t], zk, zkm);
+        pair_phase(Xa[t], Xb[t], w32(t), g0[t], zk, zkm);
         A[t] = zk;
         if (t >= 1 && t <= 7) {
           A[16 - t] = zkm;
@@ -540,7 +530,7 @@ struct FusedKernel {
       // set S_{J/2}: k = J/2 + t*J <-> J/2 + (15-t)*J, t = 0..7
       MI_UNROLL
       for (int t = 0; t < 8; ++t) {
-        pair_phase(Xa[9 + t], Xb[9 + t], cmul(Wb, w32(t)), t < 7 ? gv[9 + t] : gx, B[t], B[15 - t]);
+        pair_phase(Xa[9 + t], Xb[9 + t], cmul(Wb, w32(t)), g0[9 + t], B[t], B[15 - t]);
       }
     }
   }
@@ -695,8 +685,6 @@ struct FusedKernel {
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
     cf A[16], B[16];
-    f4 gv[16], gx;
-    load_g(ft.GT, ft.G0, 0, tid, gv, gx);
     fwd_last(lds, blkA, blkB, A, B);
     MI_STAMP(sb + 7);
     // no barrier: the next LDS access is this thread writing its own two blocks
@@ -715,13 +703,15 @@ struct FusedKernel {
     // --------------------------- per output phase ------------------------
     const bool evenOc = (b.Oc & 1) == 0;
     for (int p = 0; p < g.P; ++p) {
+      const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
+      const f4 *g0 = ft.G0 + p * 17;
       float *plane = scr_c + static_cast<long long>(p) * g.Bc;
       int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
       MI_OPAQUE_VGPR(tl);
       if (tid == 0) {
-        phase_inputs<true>(Xa, Xb, Wa, Wb, gv, gx, A, B);
+        phase_inputs<true>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       } else {
-        phase_inputs<false>(Xa, Xb, Wa, Wb, gv, gx, A, B);
+        phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       }
       const int sp = sb + 9 + 10 * (p & 3);
       (void)sp;
@@ -748,9 +738,6 @@ struct FusedKernel {
         MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
-      if (p + 1 < g.P) {
-        load_g(ft.GT, ft.G0, p + 1, tl, gv, gx);  // ahead of this phase's plane stores
-      }
       if (evenOc) {
         inv_last<true>(plane, b.Oc, lds, ft.tw, tl);
       } else {

@@ -42,7 +42,7 @@ void BuildFusedLayout(FilterTables *t) {
   t->WmT.assign(T, cf{1.0f, 0.0f});
   t->blockB.assign(T, 0);
   t->GT.assign(static_cast<std::size_t>(P) * 16 * T, f4{0.0f, 0.0f, 0.0f, 0.0f});
-  t->G0.assign(static_cast<std::size_t>(P), f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->G0.assign(static_cast<std::size_t>(P) * 17, f4{0.0f, 0.0f, 0.0f, 0.0f});
   t->Wb = t->Wm[J / 2];
   auto pair = [&](int p, int k) {
     const cf gs = t->Gs[static_cast<std::size_t>(p) * K + k];
@@ -60,13 +60,13 @@ void BuildFusedLayout(FilterTables *t) {
       }
     }
   }
-  // thread 0 (column 0): S_0 pairs s = 0..8, then S_{J/2} pairs 0..6; the 17th goes to G0
   for (int p = 0; p < P; ++p) {
-    for (int s = 0; s < 16; ++s) {
-      const int k = s <= 8 ? s * J : J / 2 + (s - 9) * J;
-      t->GT[(static_cast<std::size_t>(p) * 16 + s) * T] = pair(p, k);
+    for (int s = 0; s <= 8; ++s) {
+      t->G0[static_cast<std::size_t>(p) * 17 + s] = pair(p, s * J);
     }
-    t->G0[p] = pair(p, J / 2 + 7 * J);
+    for (int s = 0; s < 8; ++s) {
+      t->G0[static_cast<std::size_t>(p) * 17 + 9 + s] = pair(p, J / 2 + s * J);
+    }
   }
   t->hasFused = true;
 }

@@ -32,7 +32,7 @@ struct FilterTables {
   std::vector<cf> WmT;      // [T]
   std::vector<int> blockB;  // [T]
   std::vector<f4> GT;       // [P][16][T]
-  std::vector<f4> G0;       // [P]
+  std::vector<f4> G0;       // [P][17]
   cf Wb{1.0f, 0.0f};
 };
 
