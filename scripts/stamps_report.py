@@ -9,7 +9,8 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
-os.environ["MIUPS_LIB"] = str(ROOT / "totton-rasp-gpu-dsp_amd" / "lib_ablate" / "libmi_upsampler_STAMPS.so")
+os.environ.setdefault("MIUPS_LIB", str(ROOT / "totton-rasp-gpu-dsp_amd" / "lib_ablate" / "libmi_upsampler_STAMPS.so"))
+BRIEF = os.environ.get("STAMPS_BRIEF") == "1"
 sys.path.insert(0, str(ROOT))
 import totton_rasp_gpu_dsp_amd as ups  # noqa: E402
 
@@ -31,7 +32,7 @@ for p in range(4):
                             "sync"]):
         names[9 + 10 * p + k] = f"p{p}.{nm}"
 order = sorted(names)
-for wg in (0, 5, 17):
+for wg in (() if BRIEF else (0, 5, 17)):
     for wave in (0, 3, 7):
         t = st[wg, wave]
         print(f"--- wg {wg} wave {wave}: total {t[129] - t[0]} cycles; epilogue {t[129] - t[128]}")

@@ -347,7 +347,12 @@ struct FusedKernel {
       const cf y = v[out_pos<R>(u)];
       if constexpr (kEvenOc) {
         if (n >= Oc) {
+#if defined(MIUPS_EXP_NT_SCRATCH) && !defined(MIUPS_HOST_EMU)  // experiment switch (profiles/)
+          __builtin_nontemporal_store(y.x, plane + (n - Oc));
+          __builtin_nontemporal_store(y.y, plane + (n - Oc) + 1);
+#else
           *reinterpret_cast<cf *>(plane + (n - Oc)) = y;
+#endif
         }
       } else {
         if (n >= Oc) {
@@ -580,7 +585,11 @@ struct FusedKernel {
           MI_UNROLL
           for (int e = 0; e < VPT; ++e) {
             const int pp = e / cg, cc = e - pp * cg;
+#if defined(MIUPS_EXP_NT_SCRATCH) && !defined(MIUPS_HOST_EMU)  // experiment switch (profiles/)
+            v[d][e] = __builtin_nontemporal_load(scr + (cc * g.P + q * pg + pp) * g.Bc + i);
+#else
             v[d][e] = scr[(cc * g.P + q * pg + pp) * g.Bc + i];
+#endif
           }
         }
       }
@@ -702,7 +711,12 @@ struct FusedKernel {
 
     // --------------------------- per output phase ------------------------
     const bool evenOc = (b.Oc & 1) == 0;
-    for (int p = 0; p < g.P; ++p) {
+    // Workgroups that share an XCD run in near lockstep and would all pull the same
+    // spectrum lines out of the same L2 channels at the same moment (measured: 3.5x
+    // slower phase-spectrum loads). Each starts its phase loop at a different phase.
+    const int rot = (MI_BID_X >> 3) + cc;
+    for (int pi = 0; pi < g.P; ++pi) {
+      const int p = (pi + rot) % g.P;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
       const f4 *g0 = ft.G0 + p * 17;
       float *plane = scr_c + static_cast<long long>(p) * g.Bc;
@@ -713,7 +727,7 @@ struct FusedKernel {
       } else {
         phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
       }
-      const int sp = sb + 9 + 10 * (p & 3);
+      const int sp = sb + 9 + 10 * (pi & 3);
       (void)sp;
       MI_STAMP(sp + 0);
       int ba = blkA, bb = blkB;
@@ -759,7 +773,11 @@ struct FusedKernel {
     // Placement only affects speed; any mapping is a bijection onto the items.
     const int nwg = MI_GDIM_X, hw = MI_BID_X;
     const int xq = nwg / 8, xr = nwg % 8, xk = hw % 8;
+#if defined(MIUPS_EXP_NO_XCD_MAP)  // experiment switch (profiles/): identity mapping
+    const int local = hw + 0 * (xq + xr + xk);
+#else
     const int local = xk * xq + (xk < xr ? xk : xr) + hw / 8;
+#endif
     // item = (stream*groups + group) * blocks + block   (block fastest)
     const int item = io.item0 + local;
     const int sg = item / io.blocks;
