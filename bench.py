@@ -23,6 +23,10 @@ own hipEvent duration on the launching stream; `cpu_baseline` times the
 reference's own C++ (oracle/_ref, built from /root/reference in the build
 container) -- or the C restatement when that library is absent -- on one host
 core over a bounded sample of the same workload.
+
+`--dry-run` exercises everything except the GPU (rank/stream sharding,
+rendezvous, barriers, max-reduce, JSON assembly) with a synthetic per-rank
+time; tests/test_distributed.py uses it with world_size 2 on CPU.
 """
 from __future__ import annotations
 
@@ -49,7 +53,7 @@ CONFIGS = {
     5: ("filter_48k_8x_160000_linear_phase.json", 1, 32, 64, "48k 8x linear 160k-tap, 32ch + EQ"),
 }
 
-EQ_PROFILE = (ROOT / "tests" / "golden" / "g4_eq_profiles.json")
+EQ_PROFILE = ROOT / "tests" / "golden" / "g4_eq_profiles.json"
 
 
 class Hip:
@@ -88,6 +92,12 @@ class Hip:
         s = C.c_void_p()
         self.check(self.lib.hipStreamCreate(C.byref(s)), "hipStreamCreate")
         return s.value
+
+
+def stream_ids(rank: int, streams_per_gpu: int) -> list[int]:
+    """Global ids of the independent streams rank `rank` owns (static
+    partition by stream, nothing shared between ranks but the read-only filter)."""
+    return [rank * streams_per_gpu + s for s in range(streams_per_gpu)]
 
 
 def synth_pcm(config_id: int, stream_id: int, frames: int, channels: int) -> np.ndarray:
@@ -131,6 +141,43 @@ def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
                       f"{dt:.1f} s, single thread)"}
 
 
+def run_gpu(args, ups, cfg, fpath, rank, local_rank, streams, channels, blocks, barrier):
+    """Timed region on this rank's GPU. Returns (elapsed_s, kernel stats, engine path)."""
+    hip = Hip()
+    device = local_rank % ups.device_count()
+    hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
+    filt = ups.Filter(fpath, device=device)
+    use_eq = args.eq or args.config in (3, 5)
+    if use_eq:
+        text = json.loads(EQ_PROFILE.read_text())["opra10"]
+        filt.set_eq(text, 768000.0 if "48k" in fpath.name else 705600.0)
+    eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
+    # synthetic PCM, resident in HBM before anything is timed
+    in_stride, out_stride = eng.in_bytes(blocks), eng.out_bytes(blocks)
+    d_in = hip.malloc(in_stride * streams)
+    d_out = hip.malloc(out_stride * streams)
+    for s, sid in enumerate(stream_ids(rank, streams)):
+        hip.h2d(d_in + s * in_stride, synth_pcm(args.config, sid, blocks * eng.in_frames, channels))
+    stream = hip.stream()
+    for _ in range(args.warmup):
+        eng.process_device(d_in, d_out, blocks, stream)
+    eng.enable_kernel_timing(max(args.steps, 1))
+    hip.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.process_device(d_in, d_out, blocks, stream)
+    hip.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kstat = eng.kernel_ms_stats()
+    # sanity on the last output (not timed): non-trivial
+    tail = np.empty(min(cfg["block_size"] * channels, 65536), dtype="<i4")
+    hip.d2h(tail, d_out)
+    assert np.abs(tail.astype(np.int64)).max() > 0, "output is all zeros"
+    return elapsed, kstat, eng.path, use_eq
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +189,7 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eq", action="store_true", help="fold the 10-band EQ profile into the filter")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: synthetic per-rank time (CPU tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,69 +205,61 @@ def main() -> int:
     # product library first: it brings in the HIP runtime it was built against
     import totton_rasp_gpu_dsp_amd as ups
 
-    if ups.device_count() < 1:
+    if not args.dry_run and ups.device_count() < 1:
         print("bench.py: no HIP device (the upsampler has no CPU path)", file=sys.stderr)
         return 1
-    hip = Hip()
-    device = local_rank % ups.device_count()
-    hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
 
     dist = None
     if world > 1:
-        import torch.distributed as dist  # control plane only (gloo): rendezvous, barriers, max-reduce
         import torch
+        import torch.distributed as dist  # control plane only (gloo): rendezvous, barriers, max-reduce
 
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo reports its connection state on stdout; keep stdout for the ONE json line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
     fname, streams, channels, blocks, desc = CONFIGS[args.config]
     streams = args.streams or streams
     blocks = args.blocks or blocks
     fpath = ROOT / "data" / "coefficients" / fname
-    filt = ups.Filter(fpath, device=device)
-    cfg = filt.config
+    ok, msg, cfg = ups.read_filter(fpath)
+    if not ok:
+        print(f"bench.py: {msg}", file=sys.stderr)
+        return 1
     L, B, N = cfg["upsample_factor"], cfg["block_size"], cfg["fft_size"]
-    use_eq = args.eq or args.config in (3, 5)
-    if use_eq:
-        text = json.loads(EQ_PROFILE.read_text())["opra10"]
-        fs_out = 768000.0 if "48k" in fname else 705600.0
-        filt.set_eq(text, fs_out)
-    eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
-    nin = eng.in_frames
 
-    # synthetic PCM, resident in HBM before anything is timed
-    in_stride, out_stride = eng.in_bytes(blocks), eng.out_bytes(blocks)
-    d_in = hip.malloc(in_stride * streams)
-    d_out = hip.malloc(out_stride * streams)
-    for s in range(streams):
-        pcm = synth_pcm(args.config, rank * streams + s, blocks * nin, channels)
-        hip.h2d(d_in + s * in_stride, pcm)
-    stream = hip.stream()
+    if args.dry_run:
+        barrier()
+        elapsed = 0.010 * (rank + 1)  # deterministic, rank-dependent: the max-reduce must pick the last rank
+        barrier()
+        kstat = {"avg": elapsed * 1e3 / max(args.steps, 1), "min": 0.0, "count": 0}
+        path, use_eq = "dry-run", False
+    else:
+        elapsed, kstat, path, use_eq = run_gpu(args, ups, cfg, fpath, rank, local_rank, streams, channels, blocks, barrier)
 
-    def barrier():
-        hip.sync()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        eng.process_device(d_in, d_out, blocks, stream)
-    eng.enable_kernel_timing(max(args.steps, 1))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.process_device(d_in, d_out, blocks, stream)
-    hip.sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    owned = stream_ids(rank, streams)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kstat = eng.kernel_ms_stats()
-
-    # sanity on the last output (not timed): finite, non-trivial
-    tail = np.empty(min(B * channels, 65536), dtype="<i4")
-    hip.d2h(tail, d_out)
-    assert np.abs(tail.astype(np.int64)).max() > 0, "output is all zeros"
+        ids = [None] * world
+        dist.all_gather_object(ids, owned)
+        all_ids = sorted(i for part in ids for i in part)
+    else:
+        all_ids = owned
+    assert all_ids == list(range(world * streams)), "stream partition must be disjoint and complete"
 
     units_rank = blocks * streams * channels                 # channel-blocks per launch on this GPU
     samples_step = units_rank * B * world                    # whole job, all ranks
@@ -243,17 +283,18 @@ def main() -> int:
         "config": {"workload": f"configs[{args.config - 1}]: {desc}", "filter": fname, "taps": cfg["taps"],
                    "fft_size": N, "block_size": B, "upsample_factor": L, "streams_per_gpu": streams,
                    "channels": channels, "blocks_per_channel": blocks, "pcm": "s32 interleaved in/out",
-                   "eq": bool(use_eq), "kernel_path": eng.path, "parallelism": f"streams sharded over {world} GPU(s), no collective"},
+                   "eq": bool(use_eq), "kernel_path": path, "streams_total": world * streams,
+                   "parallelism": f"streams sharded over {world} GPU(s), no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                      "kernel_ms_avg": round(kstat["avg"], 5), "kernel_ms_min": round(kstat["min"], 5),
                      "kernel_launches_timed": kstat["count"],
                      "algorithmic_bytes_per_launch": int(bytes_launch),
                      "note": "bytes = units*4B(1+1/L) + 8(N/2+1); duration = hipEvent pair around the "
-                             f"{eng.path} kernel(s) on the launching stream, rank 0"},
+                             f"{path} kernel(s) on the launching stream, rank 0"},
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             result["cpu_baseline"] = cpu_baseline(fpath, args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -181,15 +181,28 @@ int mi_eq_biquad(int enabled, int type, double freq, double gain, double q, doub
 int mi_eq_response_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_reim);
 int mi_eq_magnitude_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_mag);
 
+/* Layout facts of the fused kernel (K = 2^log2k complex points per channel-block,
+ * 5 <= log2k <= 14), exported so that the CPU tests can verify bank-conflict
+ * freedom and the mirror pairing without a GPU:
+ *   mi_lds_swizzle        LDS word index -> physical word index
+ *   mi_fused_set_of_block sixteen-bin set {a + t*K/16} held by LDS block b after the forward FFT
+ *   mi_fused_block_a      first LDS block of thread tau in the two passes next to the spectral stage */
+int mi_lds_swizzle(int word_index);
+int mi_fused_set_of_block(int block, int log2k);
+int mi_fused_block_a(int tau, int log2k);
+
 /* Load-time tables as the kernels will see them (host build, for inspection):
  * geometry[10] = log2k,K,M,P,S,Oc,Bc,n_in,B,hist_frames; which: 0 Gs, 1 Gc,
- * 2 Wm, 3 tw (interleaved re,im float32). apo_text may be NULL. */
+ * 2 Wm, 3 tw in natural bin order; 4 WmT, 5 GT, 6 G0 in the fused kernel's
+ * thread order (empty outside its range); all interleaved re,im float32.
+ * mi_tables_block_b: the per-thread LDS block table. apo_text may be NULL. */
 typedef struct mi_tables mi_tables;
 int mi_tables_build(const char *json_path, int flags, const char *apo_text, double fs_out, mi_tables **out, char *err,
                     size_t errcap);
 int mi_tables_geometry(const mi_tables *t, int *geometry10);
 size_t mi_tables_size(const mi_tables *t, int which); /* complex elements */
 int mi_tables_copy(const mi_tables *t, int which, float *out_reim, size_t cap_complex);
+int mi_tables_block_b(const mi_tables *t, int *out, size_t cap);
 void mi_tables_free(mi_tables *t);
 
 #ifdef __cplusplus

@@ -1,0 +1,109 @@
+"""CPU pre-flight of the HIP kernels: the product's device headers compiled with
+-DMIUPS_HOST_EMU (tests/emu/emu_driver.cpp: one OS thread per GPU thread, real
+barriers, exact-size buffers) under AddressSanitizer + UBSan, compared with fp64
+truth. This is how kernel indexing is checked before a kernel ever runs on a
+GPU box; it is test infrastructure, not a product code path (the product library
+contains no CPU compute path -- see test_host_logic.py)."""
+from __future__ import annotations
+
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+EMU_DIR = ROOT / "tests" / "emu"
+EMU_BIN = ROOT / "tests" / "_emu" / "emu_driver"
+FMT = {"f32": 0, "s16": 1, "s24": 2, "s32": 3}
+
+
+@pytest.fixture(scope="session")
+def emu():
+    r = subprocess.run(["make", "-C", str(EMU_DIR)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return EMU_BIN
+
+
+def run_emu(emu, tmp_path, json_path, x_bytes, streams, channels, blocks, calls, path, in_fmt="f32", out_fmt="f32",
+            flags=0):
+    (tmp_path / "in.bin").write_bytes(x_bytes)
+    r = subprocess.run([str(emu), str(json_path), str(flags), str(streams), str(channels), str(FMT[in_fmt]),
+                        str(FMT[out_fmt]), str(blocks), str(calls), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"),
+                        path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]  # ASan/UBSan reports land here
+    return (tmp_path / "out.bin").read_bytes()
+
+
+CASES = [
+    # fft, taps, L, path, streams, channels, blocks, calls
+    (16, 5, 1, "staged", 1, 1, 2, 2),
+    (16, 5, 2, "staged", 1, 2, 2, 2),
+    (16, 5, 3, "staged", 1, 1, 2, 2),     # factor that does not divide fft: P = 1, S = 3
+    (64, 17, 1, "fused", 1, 1, 3, 2),     # K = 32: one thread
+    (128, 33, 1, "fused", 1, 2, 2, 2),    # K = 64
+    (256, 65, 2, "fused", 2, 2, 2, 2),
+    (512, 130, 1, "fused", 1, 2, 2, 2),   # odd history length
+    (1024, 257, 1, "fused", 1, 1, 2, 2),
+    (1024, 257, 4, "fused", 2, 3, 3, 2),  # odd channel count, chunked launch
+    (1024, 257, 16, "fused", 1, 2, 4, 1),
+    (1024, 257, 4, "staged", 2, 2, 2, 2),
+    (4096, 1025, 2, "fused", 1, 8, 1, 2),  # 8-channel group
+    (4096, 1025, 8, "fused", 1, 12, 2, 1),  # 12 channels -> groups of 6
+    (8192, 2049, 1, "fused", 1, 1, 1, 2),  # K = 4096 (radices 16,16,16)
+]
+
+
+@pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", CASES)
+def test_emulated_kernels_match_truth(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls):
+    rng = np.random.default_rng(fft * 31 + L)
+    h = rng.standard_normal(taps).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    x = rng.standard_normal((calls, streams, blocks * nin, channels)).astype(np.float32)
+    y = np.frombuffer(run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, calls, path), np.float32)
+    y = y.reshape(calls, streams, blocks * block, channels)
+    for s in range(streams):
+        for c in range(channels):
+            truth = O.truth_stream(x[:, s, :, c].reshape(-1), h, L, calls * blocks, block).reshape(-1)
+            assert rel_err(y[:, s, :, c].reshape(-1), truth) <= 1e-5
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt", [("s32", "s32"), ("s16", "s16"), ("s24", "s24"), ("s16", "f32"), ("f32", "s24")])
+def test_emulated_pcm_formats(emu, O, make_filter, tmp_path, in_fmt, out_fmt):
+    rng = np.random.default_rng(3)
+    fft, taps, L = 1024, 257, 4
+    h = (rng.standard_normal(taps) * 0.05).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks, ch = block // L, 3, 2
+    xf = np.clip(rng.standard_normal((blocks * nin, ch)) * 0.2, -1, 1).astype(np.float32)
+    raw = xf.tobytes() if in_fmt == "f32" else O.float_to_pcm(xf.reshape(-1), in_fmt).tobytes()
+    xin = xf if in_fmt == "f32" else O.pcm_to_float(np.frombuffer(raw, np.uint8), in_fmt).reshape(-1, ch)
+    out = run_emu(emu, tmp_path, p, raw, 1, ch, blocks, 1, "fused", in_fmt, out_fmt)
+    # same kernels with float output give the pre-conversion values: the PCM bytes
+    # must equal the oracle's conversion of exactly those floats
+    yf = np.frombuffer(run_emu(emu, tmp_path, p, raw, 1, ch, blocks, 1, "fused", in_fmt, "f32"), np.float32)
+    if out_fmt == "f32":
+        got = np.frombuffer(out, np.float32)
+        np.testing.assert_array_equal(got, yf)
+    else:
+        np.testing.assert_array_equal(np.frombuffer(out, np.uint8), O.float_to_pcm(yf, out_fmt))
+    for c in range(ch):
+        truth = O.truth_stream(xin[:, c], h, L, blocks, block).reshape(-1)
+        assert rel_err(yf.reshape(-1, ch)[:, c], truth) <= 1e-5
+
+
+def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
+    """44k 4x shipped filter, one stereo block through both kernel families."""
+    path = ROOT / "tests" / "golden" / "filters" / "filter_44k_4x_80000_min_phase.json"
+    h, taps, fft, block, L = O.read_filter(path)
+    nin = block // L
+    x = (np.random.default_rng(8).standard_normal((nin, 2)) * 0.2).astype(np.float32)
+    yf = np.frombuffer(run_emu(emu, tmp_path, path, x.tobytes(), 1, 2, 1, 1, "fused"), np.float32).reshape(-1, 2)
+    ys = np.frombuffer(run_emu(emu, tmp_path, path, x.tobytes(), 1, 2, 1, 1, "staged"), np.float32).reshape(-1, 2)
+    for c in range(2):
+        truth = O.truth_stream(x[:, c], h, L, 1, block).reshape(-1)
+        assert rel_err(yf[:, c], truth) <= 1e-5
+        assert rel_err(ys[:, c], truth) <= 1e-5

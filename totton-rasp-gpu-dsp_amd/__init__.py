@@ -95,6 +95,10 @@ def _load():
         "mi_tables_geometry": (i32, [vp, C.POINTER(i32)]),
         "mi_tables_size": (sz, [vp, i32]),
         "mi_tables_copy": (i32, [vp, i32, f32p, sz]),
+        "mi_tables_block_b": (i32, [vp, C.POINTER(i32), sz]),
+        "mi_lds_swizzle": (i32, [i32]),
+        "mi_fused_set_of_block": (i32, [i32, i32]),
+        "mi_fused_block_a": (i32, [i32, i32]),
         "mi_tables_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -117,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "mi_resolve_filter_path", "mi_parse_format", "mi_bytes_per_sample", "mi_pcm_to_float", "mi_float_to_pcm",
     "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
     "mi_eq_magnitude_host", "mi_tables_build", "mi_tables_geometry", "mi_tables_size", "mi_tables_copy",
-    "mi_tables_free",
+    "mi_tables_free", "mi_tables_block_b", "mi_lds_swizzle", "mi_fused_set_of_block", "mi_fused_block_a",
 ]
 
 
@@ -400,11 +404,17 @@ def build_tables(json_path, flags: int = LOAD_DEFAULT, apo_text: str | None = No
         lib.mi_tables_geometry(h, g)
         names = ["log2k", "K", "M", "P", "S", "Oc", "Bc", "n_in", "B", "hist_frames"]
         res = {"geometry": dict(zip(names, [int(v) for v in g]))}
-        for which, name in enumerate(["Gs", "Gc", "Wm", "tw"]):
+        for which, name in enumerate(["Gs", "Gc", "Wm", "tw", "WmT", "GT", "G0"]):
             n = int(lib.mi_tables_size(h, which))
             a = np.empty(n, dtype=np.complex64)
-            lib.mi_tables_copy(h, which, _f32(a.view(np.float32)), n)
+            if n:
+                lib.mi_tables_copy(h, which, _f32(a.view(np.float32)), n)
             res[name] = a
+        nb = res["WmT"].size
+        bb = (C.c_int * max(nb, 1))()
+        if nb:
+            lib.mi_tables_block_b(h, bb, nb)
+        res["blockB"] = np.array(bb[:nb], dtype=np.int64)
         return res
     finally:
         lib.mi_tables_free(h)

@@ -238,19 +238,60 @@ int mi_tables_geometry(const mi_tables *t, int *g10) {
   return MI_OK;
 }
 
+// which 0..3: natural-order tables; 4 WmT, 5 GT, 6 G0: the fused kernel's thread-order
+// copies (GT / G0 entries are {Gs, Gc} pairs = two complex values each)
 size_t mi_tables_size(const mi_tables *t, int which) {
-  const auto *v = t ? Pick(t, which) : nullptr;
+  if (!t) {
+    return 0;
+  }
+  if (which == 4) {
+    return t->tables.WmT.size();
+  }
+  if (which == 5) {
+    return 2 * t->tables.GT.size();
+  }
+  if (which == 6) {
+    return 2 * t->tables.G0.size();
+  }
+  const auto *v = Pick(t, which);
   return v ? v->size() : 0;
 }
 
 int mi_tables_copy(const mi_tables *t, int which, float *out_reim, size_t cap_complex) {
-  const auto *v = t ? Pick(t, which) : nullptr;
-  if (!v || !out_reim || cap_complex < v->size()) {
+  if (!t || !out_reim || cap_complex < mi_tables_size(t, which)) {
     return MI_ERR_ARG;
   }
-  std::memcpy(out_reim, v->data(), v->size() * sizeof(miups::cf));
+  const void *src = nullptr;
+  if (which == 4) {
+    src = t->tables.WmT.data();
+  } else if (which == 5) {
+    src = t->tables.GT.data();
+  } else if (which == 6) {
+    src = t->tables.G0.data();
+  } else {
+    const auto *v = Pick(t, which);
+    if (!v) {
+      return MI_ERR_ARG;
+    }
+    src = v->data();
+  }
+  std::memcpy(out_reim, src, mi_tables_size(t, which) * sizeof(miups::cf));
   return MI_OK;
 }
+
+int mi_tables_block_b(const mi_tables *t, int *out, size_t cap) {
+  if (!t || !out || cap < t->tables.blockB.size()) {
+    return MI_ERR_ARG;
+  }
+  std::memcpy(out, t->tables.blockB.data(), t->tables.blockB.size() * sizeof(int));
+  return MI_OK;
+}
+
+int mi_lds_swizzle(int word_index) { return miups::lds_swz(word_index); }
+
+int mi_fused_set_of_block(int block, int log2k) { return miups::FusedSetOfBlock(block, log2k); }
+
+int mi_fused_block_a(int tau, int log2k) { return miups::FusedBlockA(tau, log2k); }
 
 void mi_tables_free(mi_tables *t) { delete t; }
 

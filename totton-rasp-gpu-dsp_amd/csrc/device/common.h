@@ -88,6 +88,15 @@ struct alignas(16) f4 {
   float x, y, z, w;
 };
 
+// LDS word (8-byte complex) index swizzle of the fused kernel. Every pass
+// touches, per wave instruction, either 32 consecutive words or 16-word blocks
+// whose block index varies across lanes; the XOR terms spread both patterns over
+// all banks for ds_read_b64 (64 banks, 32-lane groups) and ds_write_b64
+// (32 banks, 16-lane groups). Verified by tests/test_lds_layout.py.
+MI_HD int lds_swz(int i) {
+  return i ^ ((i >> 4) & 15) ^ ((i >> 5) & 8) ^ ((((i >> 8) ^ (i >> 9)) & 1) << 4);
+}
+
 // Tables read by the fused kernel, laid out per thread (the kernel's thread ->
 // frequency-bin assignment is fixed, so the host stores everything in the
 // order lanes consume it: every table load is lane-contiguous).

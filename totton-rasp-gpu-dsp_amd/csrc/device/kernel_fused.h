@@ -74,15 +74,6 @@ __device__ unsigned long long mi_stamps[32][8][192];
 
 namespace miups {
 
-// LDS word (8-byte complex) index swizzle. Every pass touches, per wave
-// instruction, either 32 consecutive words or 16-word blocks whose block index
-// varies across lanes; the XOR terms spread both patterns over all banks for
-// ds_read_b64 (64 banks, 32-lane groups) and ds_write_b64 (32 banks, 16-lane
-// groups). Verified exhaustively by tests/test_lds_layout.py.
-MI_HD int lds_swz(int i) {
-  return i ^ ((i >> 4) & 15) ^ ((i >> 5) & 8) ^ ((((i >> 8) ^ (i >> 9)) & 1) << 4);
-}
-
 // exp(-2*pi*i*t/32), t = 0..16
 MI_DEVICE cf w32(int t) {
   constexpr float c[17] = {1.0f,
