@@ -217,6 +217,12 @@ int main(int argc, char **argv) {
           cg = d;
         }
       }
+      if (const char *force = std::getenv("EMU_CG")) {  // tests: narrower groups, as Engine::PickChannelGroup may choose
+        const int v = std::atoi(force);
+        if (v > 0 && channels % v == 0) {
+          cg = v;
+        }
+      }
       const unsigned wgs = static_cast<unsigned>(blocks) * streams * (channels / cg);
       const unsigned chunk = wgs > 3 ? (wgs + 1) / 2 : wgs;  // exercise the chunked launch (item0 > 0)
       std::vector<float> scratch(static_cast<size_t>(chunk) * cg * g.B);

@@ -95,6 +95,26 @@ def test_emulated_pcm_formats(emu, O, make_filter, tmp_path, in_fmt, out_fmt):
         assert rel_err(yf.reshape(-1, ch)[:, c], truth) <= 1e-5
 
 
+@pytest.mark.parametrize("channels,cg,out_fmt", [(8, 4, "f32"), (8, 4, "s32"), (8, 2, "f32"), (12, 4, "s32"), (2, 1, "s32")])
+def test_emulated_narrow_channel_groups(emu, O, make_filter, tmp_path, monkeypatch, channels, cg, out_fmt):
+    """Engine::PickChannelGroup may hand a workgroup fewer channels than a frame has:
+    the epilogue then writes cg-sample runs into frames that other workgroups complete."""
+    monkeypatch.setenv("EMU_CG", str(cg))
+    rng = np.random.default_rng(channels * 10 + cg)
+    fft, taps, L = 1024, 257, 4
+    h = (rng.standard_normal(taps) * 0.05).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks = block // L, 3
+    x = np.clip(rng.standard_normal((1, 1, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    out = run_emu(emu, tmp_path, p, x.tobytes(), 1, channels, blocks, 1, "fused", "f32", out_fmt)
+    y = (np.frombuffer(out, np.float32) if out_fmt == "f32" else O.pcm_to_float(np.frombuffer(out, np.uint8), out_fmt))
+    y = y.reshape(blocks * block, channels)
+    for c in range(channels):
+        truth = O.truth_stream(x[0, 0, :, c], h, L, blocks, block).reshape(-1)
+        assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + (0 if out_fmt == "f32" else 2.0**-31)
+
+
 def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
     """44k 4x shipped filter, one stereo block through both kernel families."""
     path = ROOT / "tests" / "golden" / "filters" / "filter_44k_4x_80000_min_phase.json"

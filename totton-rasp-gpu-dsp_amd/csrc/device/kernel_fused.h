@@ -588,9 +588,14 @@ struct FusedKernel {
       for (int d = 0; d < kDepth; ++d) {
         const int unit = base + d * T;
         if (unit < units) {
-          char *dst = out_blk + static_cast<long long>(unit) * (VPT * 4);
+          // value e = (phase pp, channel cc) of frame (unit*pg + pp): the group's cg
+          // channels of one frame are contiguous, frames are io.channels samples apart
+          // (when cg == io.channels everything is one contiguous run)
+          const long long frame0 = static_cast<long long>(unit) * pg;
           MI_UNROLL
           for (int e = 0; e < VPT; e += 4) {
+            const int pp = e / cg, cc = e - pp * cg;
+            char *dst = out_blk + ((frame0 + pp) * io.channels + cc) * 4 - 4 * e;
             if constexpr (FMT == kF32) {
               *reinterpret_cast<f4 *>(dst + 4 * e) = f4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
             } else {
@@ -628,7 +633,10 @@ struct FusedKernel {
     const bool pow2 = (cg & (cg - 1)) == 0 && (g.P & (g.P - 1)) == 0;
     const int pg = pow2 ? (cg * g.P <= 16 ? g.P : (16 / cg > 0 ? 16 / cg : 1)) : 1;
     const int vpt = cg * pg;
-    const bool vec = pow2 && io.out_vec_ok && cg == io.channels && cg <= 16 && vpt >= 4 &&
+    // 16-byte stores need every 4-value run contiguous and aligned: the group is the whole
+    // frame, or groups and frames are both multiples of 4 channels
+    const bool runs_ok = cg == io.channels || (cg % 4 == 0 && io.channels % 4 == 0);
+    const bool vec = pow2 && io.out_vec_ok && runs_ok && cg <= 16 && vpt >= 4 &&
                      (io.out_fmt == kF32 || io.out_fmt == kS32);
     if (vec) {
       if (io.out_fmt == kF32) {

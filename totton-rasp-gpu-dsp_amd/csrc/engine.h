@@ -94,10 +94,12 @@ class Engine {
  private:
   Engine() = default;
   bool EnsureWork(std::size_t items, std::string *error);
+  void PickChannelGroup(std::size_t blocks);
 
   std::shared_ptr<DeviceFilter> filter_;
   int streams_ = 1, channels_ = 1, inFmt_ = kF32, outFmt_ = kF32;
   bool fused_ = false;
+  int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
   float *scratch_ = nullptr;       // fused path: fp32 staging planes
   std::size_t scratchBytes_ = 0;

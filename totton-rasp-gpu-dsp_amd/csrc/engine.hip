@@ -363,8 +363,7 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->outFmt_ = outFmt;
   const Geometry &g = e->filter_->geometry();
   e->fused_ = e->filter_->hasFused() && FusedCovers(g, channels, inFmt, outFmt);
-  // channel group per workgroup: the largest divisor of `channels` that is <= 8, so that a
-  // group's samples of one frame are one contiguous run (whole frames when channels <= 8)
+  // channel group per workgroup is chosen per call (PickChannelGroup); start with the widest
   e->cg_ = 1;
   for (int d = 1; d <= 8 && d <= channels; ++d) {
     if (channels % d == 0) {
@@ -372,6 +371,11 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
     }
   }
   e->groups_ = channels / e->cg_;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->filter_->device()) != hipSuccess || cus <= 0) {
+    cus = 256;
+  }
+  e->cuCount_ = cus;
   e->histStride_ = static_cast<std::size_t>(g.hist_frames) * channels * pcm_bytes(inFmt);
   const std::size_t bytes = std::max<std::size_t>(e->histStride_ * streams, 16);
   for (int i = 0; i < 2; ++i) {
@@ -428,6 +432,34 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
   return true;
 }
 
+// Channels per workgroup for this call. Wider groups write longer contiguous runs
+// per frame (whole 32-byte sectors from 8 four-byte channels) but mean fewer
+// workgroups; a group is only narrowed while the launch would otherwise leave CUs
+// without a resident workgroup, and never below a 16-byte run.
+void Engine::PickChannelGroup(std::size_t blocks) {
+  const Geometry &g = filter_->geometry();
+  const int threads = std::max(g.K / 32, 1);
+  const int byLds = std::max(1, (160 * 1024) / std::max(g.K * 8, 1));
+  const int byWaves = std::max(1, 8 / std::max(threads / 64, 1));
+  const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
+  const int ob = pcm_bytes(outFmt_);
+  int pick = 0, narrowest = 0;
+  for (int d = std::min(8, channels_); d >= 1; --d) {
+    if (channels_ % d != 0 || !(d * ob >= 16 || d == channels_)) {
+      continue;
+    }
+    narrowest = d;
+    if (pick == 0 && blocks * streams_ * static_cast<std::size_t>(channels_ / d) >= capacity) {
+      pick = d;
+    }
+  }
+  cg_ = pick ? pick : std::max(narrowest, 1);
+  if (channels_ % cg_ != 0) {
+    cg_ = 1;
+  }
+  groups_ = channels_ / cg_;
+}
+
 bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, std::size_t outStride,
                            std::size_t blocks, void *hipStream, std::string *error) {
   if (!dIn || !dOut || blocks == 0) {
@@ -482,6 +514,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   if (fused_) {
     // one workgroup per (block, stream, channel group); launches are chunked so
     // that the fp32 staging planes (cg * B floats per workgroup) stay bounded
+    PickChannelGroup(blocks);
     const std::size_t wgs = static_cast<std::size_t>(blocks) * streams_ * groups_;
     const std::size_t perWg = static_cast<std::size_t>(cg_) * g.B * sizeof(float);
     const std::size_t budget = static_cast<std::size_t>(1024) << 20;
