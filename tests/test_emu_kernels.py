@@ -115,6 +115,37 @@ def test_emulated_narrow_channel_groups(emu, O, make_filter, tmp_path, monkeypat
         assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + (0 if out_fmt == "f32" else 2.0**-31)
 
 
+@pytest.mark.parametrize("fft,taps,L,channels,cg,out_fmt", [
+    # frames per phase % 4 == 0: register-transposed form (epilogue_quad)
+    (16384, 4001, 4, 8, 8, "s32"),    # R = 32 planes
+    (32768, 8001, 8, 8, 4, "f32"),    # narrow group: 16-byte runs inside wider frames
+    (65536, 16001, 16, 2, 2, "s32"),  # cg == channels == 2: vectors straddle phases
+    (16384, 4001, 4, 16, 8, "f32"),   # two groups per frame
+    # 3095 frames per phase: LDS-tiled form (epilogue_tiled), last tile partial
+    (16384, 4005, 4, 8, 8, "s32"),
+    (32768, 8009, 8, 8, 4, "f32"),
+    (65536, 16017, 16, 2, 2, "s32"),
+    (16384, 4005, 4, 16, 8, "f32"),
+])
+def test_emulated_wide_epilogue(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, channels, cg, out_fmt):
+    """More than 16 staging planes per workgroup: the epilogue transposes 4x4 blocks in
+    registers (FusedKernel::epilogue_quad) or [planes][64] tiles through LDS
+    (FusedKernel::epilogue_tiled)."""
+    monkeypatch.setenv("EMU_CG", str(cg))
+    rng = np.random.default_rng(fft + channels)
+    h = (rng.standard_normal(taps) * 0.02).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks = block // L, 2
+    x = np.clip(rng.standard_normal((1, 1, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    out = run_emu(emu, tmp_path, p, x.tobytes(), 1, channels, blocks, 1, "fused", "f32", out_fmt)
+    y = (np.frombuffer(out, np.float32) if out_fmt == "f32" else O.pcm_to_float(np.frombuffer(out, np.uint8), out_fmt))
+    y = y.reshape(blocks * block, channels)
+    for c in range(channels):
+        truth = O.truth_stream(x[0, 0, :, c], h, L, blocks, block).reshape(-1)
+        assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + (0 if out_fmt == "f32" else 2.0**-31)
+
+
 def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
     """44k 4x shipped filter, one stereo block through both kernel families."""
     path = ROOT / "tests" / "golden" / "filters" / "filter_44k_4x_80000_min_phase.json"

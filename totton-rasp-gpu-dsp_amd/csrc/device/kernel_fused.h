@@ -625,12 +625,171 @@ struct FusedKernel {
       pcm_store(out_blk, FMT, static_cast<long long>(m) * io.channels + cc, scr[(cc * g.P + p) * g.Bc + i]);
     }
   }
-  static MI_DEVICE void epilogue(const Geometry &g, const IoDesc &io, int s, int c0, int blk, const float *scr, int tid) {
+  // Tiled form for many planes (R = cg*P > 16 rows): a [R][64] tile of the staging planes
+  // goes through LDS (free during the epilogue; rows padded to 65 words), read with
+  // lane-contiguous 256-byte row segments and written as 16-byte vectors in output order
+  // (for one i: p-major, channel-minor = exactly the frame layout). The loads of tile k+1
+  // are in flight while tile k is stored.
+  template <int FMT, int EPT>
+  static MI_DEVICE void epilogue_tiled(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, float *tile,
+                                       int tid) {
+    constexpr int TI = 64, LD = TI + 1;
+    const int P = g.P;
+    const int lcg = __builtin_ctz(io.cg), lR = lcg + __builtin_ctz(P);  // both powers of two here
+    const int ntiles = (g.Bc + TI - 1) / TI;
+    float v[EPT];
+    auto fetch = [&](int k) {
+      MI_UNROLL
+      for (int j = 0; j < EPT; ++j) {
+        const int x = tid + j * T, row = x / TI, col = x - row * TI, i = k * TI + col;
+        v[j] = (i < g.Bc) ? scr[static_cast<long long>(row) * g.Bc + i] : 0.0f;
+      }
+    };
+    fetch(0);
+    for (int k = 0; k < ntiles; ++k) {
+      MI_UNROLL
+      for (int j = 0; j < EPT; ++j) {
+        const int x = tid + j * T, row = x / TI, col = x - row * TI;
+        tile[row * LD + col] = v[j];
+      }
+      MI_SYNC();
+      if (k + 1 < ntiles) {
+        fetch(k + 1);
+      }
+      MI_UNROLL
+      for (int j = 0; j < EPT / 4; ++j) {
+        const int e4 = 4 * (tid + j * T);  // first of 4 consecutive output values of this tile
+        const int il = e4 >> lR, r0 = e4 - (il << lR), i = k * TI + il;
+        if (i < g.Bc) {
+          float w[4];
+          MI_UNROLL
+          for (int e = 0; e < 4; ++e) {
+            const int r = r0 + e, p = r >> lcg, cc = r - (p << lcg);
+            w[e] = tile[(cc * P + p) * LD + il];
+          }
+          const int p0 = r0 >> lcg, cc0 = r0 - (p0 << lcg);
+          char *dst = out_blk + ((static_cast<long long>(i) * P + p0) * io.channels + cc0) * 4;
+          if constexpr (FMT == kF32) {
+            *reinterpret_cast<f4 *>(dst) = f4{w[0], w[1], w[2], w[3]};
+          } else {
+            struct alignas(16) I4 {
+              int32_t a, b, c, d;
+            };
+            I4 o;
+            o.a = static_cast<int32_t>(pcm_clamp(w[0], 0.9999999f) * 2147483648.0f);
+            o.b = static_cast<int32_t>(pcm_clamp(w[1], 0.9999999f) * 2147483648.0f);
+            o.c = static_cast<int32_t>(pcm_clamp(w[2], 0.9999999f) * 2147483648.0f);
+            o.d = static_cast<int32_t>(pcm_clamp(w[3], 0.9999999f) * 2147483648.0f);
+            *reinterpret_cast<I4 *>(dst) = o;
+          }
+        }
+      }
+      MI_SYNC();
+    }
+  }
+  // Register-transposed form for many planes when Bc % 4 == 0: a unit is 4 consecutive
+  // i of the 4 planes that make one 16-byte run of a frame (4 x 16-byte loads, a 4x4
+  // transpose in registers, 4 x 16-byte stores). Lanes run over the R/4 runs of a frame
+  // first, so one store instruction writes whole frames (>= 128 contiguous bytes) and one
+  // load instruction reads 64-byte pieces of R/4 planes; kUnits units per thread keep
+  // kUnits*64 bytes per lane in flight (the planes come from L2/Infinity Cache/HBM with
+  // microseconds of latency: the epilogue is latency-bound unless this much is in flight).
+  template <int FMT>
+  static MI_DEVICE void epilogue_quad(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
+    constexpr int kUnits = 8;
+    const int P = g.P, cg = io.cg;
+    const int lcg = __builtin_ctz(cg), lRq = lcg + __builtin_ctz(P) - 2;  // log2(R/4)
+    const int units = (g.Bc >> 2) << lRq;
+    for (int base = tid; base < units; base += T * kUnits) {
+      f4 v[kUnits][4];
+      MI_UNROLL
+      for (int d = 0; d < kUnits; ++d) {
+        const int u = base + d * T;
+        if (u < units) {
+          const int iq = u >> lRq, r0 = (u - (iq << lRq)) << 2;
+          MI_UNROLL
+          for (int e = 0; e < 4; ++e) {
+            const int r = r0 + e, p = r >> lcg, cc = r - (p << lcg);
+            v[d][e] = *reinterpret_cast<const f4 *>(scr + static_cast<long long>(cc * P + p) * g.Bc + 4 * iq);
+          }
+        }
+      }
+      MI_UNROLL
+      for (int d = 0; d < kUnits; ++d) {
+        const int u = base + d * T;
+        if (u < units) {
+          const int iq = u >> lRq, r0 = (u - (iq << lRq)) << 2;
+          const int p0 = r0 >> lcg, cc0 = r0 - (p0 << lcg);
+          char *dst = out_blk + ((static_cast<long long>(4 * iq) * P + p0) * io.channels + cc0) * 4;
+          const long long frame_step = static_cast<long long>(P) * io.channels * 4;  // bytes from i to i+1
+          const float m[4][4] = {{v[d][0].x, v[d][1].x, v[d][2].x, v[d][3].x},
+                                 {v[d][0].y, v[d][1].y, v[d][2].y, v[d][3].y},
+                                 {v[d][0].z, v[d][1].z, v[d][2].z, v[d][3].z},
+                                 {v[d][0].w, v[d][1].w, v[d][2].w, v[d][3].w}};
+          MI_UNROLL
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (FMT == kF32) {
+              *reinterpret_cast<f4 *>(dst + e * frame_step) = f4{m[e][0], m[e][1], m[e][2], m[e][3]};
+            } else {
+              struct alignas(16) I4 {
+                int32_t a, b, c, d;
+              };
+              I4 o;
+              o.a = static_cast<int32_t>(pcm_clamp(m[e][0], 0.9999999f) * 2147483648.0f);
+              o.b = static_cast<int32_t>(pcm_clamp(m[e][1], 0.9999999f) * 2147483648.0f);
+              o.c = static_cast<int32_t>(pcm_clamp(m[e][2], 0.9999999f) * 2147483648.0f);
+              o.d = static_cast<int32_t>(pcm_clamp(m[e][3], 0.9999999f) * 2147483648.0f);
+              *reinterpret_cast<I4 *>(dst + e * frame_step) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  template <int FMT>
+  static MI_DEVICE bool epilogue_tiled_dispatch(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr,
+                                                float *tile, int tid) {
+    const int ept = io.cg * g.P * 64 / T;  // tile values per thread
+    switch (ept) {
+      case 4: epilogue_tiled<FMT, 4>(g, io, out_blk, scr, tile, tid); return true;
+      case 8: epilogue_tiled<FMT, 8>(g, io, out_blk, scr, tile, tid); return true;
+      case 16: epilogue_tiled<FMT, 16>(g, io, out_blk, scr, tile, tid); return true;
+      case 32: epilogue_tiled<FMT, 32>(g, io, out_blk, scr, tile, tid); return true;
+      default: return false;
+    }
+  }
+
+  static MI_DEVICE void epilogue(const Geometry &g, const IoDesc &io, int s, int c0, int blk, const float *scr, cf *lds,
+                                 int tid) {
     const int ob = pcm_bytes(io.out_fmt);
     char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride +
                     (static_cast<long long>(blk) * g.B * io.channels + c0) * ob;
     const int cg = io.cg;
     const bool pow2 = (cg & (cg - 1)) == 0 && (g.P & (g.P - 1)) == 0;
+    {
+      // many planes: LDS-tiled transpose (needs 16-byte runs, a 4-byte format, the tile in LDS)
+      const int R = cg * g.P;
+      const bool runs4 = (cg % 4 == 0 && io.channels % 4 == 0) || (cg == io.channels && R % 4 == 0);
+      const bool fits = static_cast<long long>(R) * 65 * 4 <= static_cast<long long>(K) * 8 && (R * 64) % T == 0;
+      const bool wide = pow2 && R > 16 && runs4 && io.out_vec_ok && (io.out_fmt == kF32 || io.out_fmt == kS32);
+      if (wide && g.Bc % 4 == 0 && reinterpret_cast<uintptr_t>(scr) % 16 == 0) {
+        if (io.out_fmt == kF32) {
+          epilogue_quad<kF32>(g, io, out_blk, scr, tid);
+        } else {
+          epilogue_quad<kS32>(g, io, out_blk, scr, tid);
+        }
+        return;
+      }
+      if (wide && fits) {
+        float *tile = reinterpret_cast<float *>(lds);
+        const bool done = io.out_fmt == kF32 ? epilogue_tiled_dispatch<kF32>(g, io, out_blk, scr, tile, tid)
+                                             : epilogue_tiled_dispatch<kS32>(g, io, out_blk, scr, tile, tid);
+        if (done) {
+          return;
+        }
+      }
+    }
     const int pg = pow2 ? (cg * g.P <= 16 ? g.P : (16 / cg > 0 ? 16 / cg : 1)) : 1;
     const int vpt = cg * pg;
     // 16-byte stores need every 4-value run contiguous and aligned: the group is the whole
@@ -793,7 +952,7 @@ struct FusedKernel {
     MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
-    epilogue(g, io, s, c0, blk, scr, tid);
+    epilogue(g, io, s, c0, blk, scr, lds, tid);
     MI_STAMP(129);
   }
 };
