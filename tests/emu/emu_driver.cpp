@@ -210,22 +210,21 @@ int main(int argc, char **argv) {
     io.blocks = blocks;
     const unsigned items = static_cast<unsigned>(blocks) * streams * channels;
     if (fused) {
-      // same grouping rule as Engine::Create / ProcessDevice
-      int cg = 1;
-      for (int d = 1; d <= 8 && d <= channels; ++d) {
-        if (channels % d == 0) {
-          cg = d;
-        }
-      }
-      if (const char *force = std::getenv("EMU_CG")) {  // tests: narrower groups, as Engine::PickChannelGroup may choose
+      // same rule as Engine::PickChannelGroup / ProcessDevice: whole frames per workgroup for
+      // mono/stereo, else one channel per workgroup and the frames written by interleave_*_kernel
+      int cg = channels <= 2 ? channels : 1;
+      if (const char *force = std::getenv("EMU_CG")) {  // tests: other group widths the kernel supports
         const int v = std::atoi(force);
         if (v > 0 && channels % v == 0) {
           cg = v;
         }
       }
-      const unsigned wgs = static_cast<unsigned>(blocks) * streams * (channels / cg);
-      const unsigned chunk = wgs > 3 ? (wgs + 1) / 2 : wgs;  // exercise the chunked launch (item0 > 0)
-      std::vector<float> scratch(static_cast<size_t>(chunk) * cg * g.B);
+      // EMU_INKERNEL=1: keep the in-kernel epilogue for groups narrower than a frame
+      const bool ext = cg < channels && !std::getenv("EMU_INKERNEL");
+      const unsigned groups = static_cast<unsigned>(channels / cg);
+      const unsigned pairs = static_cast<unsigned>(blocks) * streams;
+      const unsigned chunk = pairs > 1 ? (pairs + 1) / 2 : pairs;  // exercise the chunked launch (item0 > 0)
+      std::vector<float> scratch(static_cast<size_t>(chunk) * channels * g.B);
       io.scratch = scratch.data();
       io.cg = cg;
       io.groups = channels / cg;
@@ -233,9 +232,51 @@ int main(int argc, char **argv) {
                        (static_cast<size_t>(g.B) * channels * 4) % 16 == 0)
                           ? 1
                           : 0;
-      for (unsigned w0 = 0; w0 < wgs; w0 += chunk) {
-        io.item0 = static_cast<int>(w0);
-        DispatchFused(g, io, t, std::min(chunk, wgs - w0));
+      IoDesc ioF = io;
+      std::vector<float> planar;
+      if (channels > 2) {  // same rule as Engine::ProcessDevice: de-interleave wide frames first
+        const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
+        const long long planeFloats = (total + 3) / 4 * 4;
+        planar.assign(static_cast<size_t>(planeFloats) * channels * streams, 0.0f);
+        const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
+        miups_emu::launch(static_cast<unsigned>(tiles) * streams, 32,
+                          static_cast<size_t>(channels) * (kPlanarTile + 1) * sizeof(float), true,
+                          [&]() { planarize_kernel(g, io, planar.data(), planeFloats, total, tiles); });
+        ioF.in = planar.data();
+        ioF.in_fmt = kF32;
+        ioF.in_planar = 1;
+        ioF.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
+        ioF.in_stream_stride = ioF.in_plane_stride * channels;
+      }
+      ioF.ext_epilogue = ext ? 1 : 0;
+      const bool quad = ioF.out_vec_ok && (outFmt == kF32 || outFmt == kS32) && (g.P * channels) % 4 == 0 && g.Bc % 4 == 0;
+      for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
+        const unsigned np = std::min(chunk, pairs - p0);
+        ioF.item0 = static_cast<int>(p0 * groups);
+        DispatchFused(g, ioF, t, np * groups);
+        if (!ext) {
+          continue;
+        }
+        if (quad) {
+          const int threads = 32, perWg = threads * 4;
+          const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels / 4);
+          const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
+          auto run = [&](auto kernel) {
+            miups_emu::launch(np * wgsPerPair, threads, 0, false, [&]() {
+              kernel(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+            });
+          };
+          if (outFmt == kF32) {
+            run(interleave_quad_kernel<kF32>);
+          } else {
+            run(interleave_quad_kernel<kS32>);
+          }
+        } else {
+          const long long total = static_cast<long long>(np) * g.B * channels;
+          miups_emu::launch(Blocks(total, 64), 64, 0, false, [&]() {
+            interleave_scalar_kernel(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np));
+          });
+        }
       }
     } else {
       const size_t row = g.K;

@@ -95,11 +95,39 @@ def test_emulated_pcm_formats(emu, O, make_filter, tmp_path, in_fmt, out_fmt):
         assert rel_err(yf.reshape(-1, ch)[:, c], truth) <= 1e-5
 
 
+@pytest.mark.parametrize("in_fmt,channels,streams", [("s16", 3, 2), ("s24", 4, 1), ("s32", 8, 1), ("f32", 5, 2)])
+def test_emulated_planarized_input(emu, O, make_filter, tmp_path, in_fmt, channels, streams):
+    """More than two channels: planarize_kernel converts history ++ new frames to one fp32
+    timeline per channel before the fused kernel runs; two calls so that the second one
+    reads real history through it."""
+    rng = np.random.default_rng(channels)
+    fft, taps, L = 1024, 301, 4   # block 724 -> 181 frames per block: odd, so unaligned timelines too
+    h = (rng.standard_normal(taps) * 0.05).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks, calls = block // L, 3, 2
+    xf = np.clip(rng.standard_normal((calls, streams, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    if in_fmt == "f32":
+        raw, xin = xf.tobytes(), xf
+    else:
+        pcm = O.float_to_pcm(xf.reshape(-1), in_fmt)
+        raw = pcm.tobytes()
+        xin = O.pcm_to_float(np.frombuffer(raw, np.uint8), in_fmt).reshape(xf.shape)
+    y = np.frombuffer(run_emu(emu, tmp_path, p, raw, streams, channels, blocks, calls, "fused", in_fmt, "f32"), np.float32)
+    y = y.reshape(calls, streams, blocks * block, channels)
+    for s in range(streams):
+        for c in range(channels):
+            truth = O.truth_stream(xin[:, s, :, c].reshape(-1), h, L, calls * blocks, block).reshape(-1)
+            assert rel_err(y[:, s, :, c].reshape(-1), truth) <= 1e-5
+
+
 @pytest.mark.parametrize("channels,cg,out_fmt", [(8, 4, "f32"), (8, 4, "s32"), (8, 2, "f32"), (12, 4, "s32"), (2, 1, "s32")])
 def test_emulated_narrow_channel_groups(emu, O, make_filter, tmp_path, monkeypatch, channels, cg, out_fmt):
-    """Engine::PickChannelGroup may hand a workgroup fewer channels than a frame has:
-    the epilogue then writes cg-sample runs into frames that other workgroups complete."""
+    """The kernel's own epilogue also supports groups narrower than a frame (it then writes
+    cg-sample runs into frames that other workgroups complete); the engine uses the
+    external interleave kernels for those instead (next test)."""
     monkeypatch.setenv("EMU_CG", str(cg))
+    monkeypatch.setenv("EMU_INKERNEL", "1")
     rng = np.random.default_rng(channels * 10 + cg)
     fft, taps, L = 1024, 257, 4
     h = (rng.standard_normal(taps) * 0.05).astype(np.float32)
@@ -113,6 +141,41 @@ def test_emulated_narrow_channel_groups(emu, O, make_filter, tmp_path, monkeypat
     for c in range(channels):
         truth = O.truth_stream(x[0, 0, :, c], h, L, blocks, block).reshape(-1)
         assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + (0 if out_fmt == "f32" else 2.0**-31)
+
+
+@pytest.mark.parametrize("channels,cg,L,taps,out_fmt", [
+    (8, 1, 4, 257, "s32"),    # vector interleave (P*C % 4 == 0, 192 frames per phase)
+    (6, 1, 2, 257, "f32"),    # 5.1: runs of four straddle phases
+    (2, 1, 4, 257, "s32"),    # stereo call too small to fill the GPU: one channel per workgroup
+    (3, 1, 4, 257, "f32"),    # P*C % 4 == 0 with odd channel count
+    (3, 1, 2, 257, "f32"),    # P*C = 6: scalar interleave
+    (8, 2, 4, 261, "s32"),    # 191 frames per phase: scalar interleave; two-channel groups
+    (4, 1, 4, 257, "s16"),    # narrow PCM: scalar interleave
+    (5, 1, 8, 257, "s24"),
+])
+def test_emulated_external_interleave(emu, O, make_filter, tmp_path, monkeypatch, channels, cg, L, taps, out_fmt):
+    """Groups narrower than a frame: the fused kernel stops at the staging planes and
+    interleave_quad_kernel / interleave_scalar_kernel write the PCM frames, chunk by chunk."""
+    monkeypatch.setenv("EMU_CG", str(cg))
+    rng = np.random.default_rng(channels * 100 + L)
+    fft = 1024
+    h = (rng.standard_normal(taps) * 0.05).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks, streams = block // L, 3, 2
+    x = np.clip(rng.standard_normal((1, streams, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    out = run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, 1, "fused", "f32", out_fmt)
+    yf = np.frombuffer(run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, 1, "fused", "f32", "f32"),
+                       np.float32)
+    if out_fmt == "f32":
+        np.testing.assert_array_equal(np.frombuffer(out, np.float32), yf)
+    else:  # the PCM bytes are the oracle's conversion of exactly the float results
+        np.testing.assert_array_equal(np.frombuffer(out, np.uint8), O.float_to_pcm(yf, out_fmt))
+    yf = yf.reshape(streams, blocks * block, channels)
+    for s in range(streams):
+        for c in range(channels):
+            truth = O.truth_stream(x[0, s, :, c], h, L, blocks, block).reshape(-1)
+            assert rel_err(yf[s, :, c], truth) <= 1e-5
 
 
 @pytest.mark.parametrize("fft,taps,L,channels,cg,out_fmt", [
@@ -132,6 +195,7 @@ def test_emulated_wide_epilogue(emu, O, make_filter, tmp_path, monkeypatch, fft,
     registers (FusedKernel::epilogue_quad) or [planes][64] tiles through LDS
     (FusedKernel::epilogue_tiled)."""
     monkeypatch.setenv("EMU_CG", str(cg))
+    monkeypatch.setenv("EMU_INKERNEL", "1")
     rng = np.random.default_rng(fft + channels)
     h = (rng.standard_normal(taps) * 0.02).astype(np.float32)
     block = fft - (taps - 1)

@@ -165,6 +165,15 @@ struct IoDesc {
   int groups;
   int item0;
   int out_vec_ok;        // 1 when out base/strides allow 16-byte aligned vector stores
+  // fused path, more than two channels: `in` is not the caller's interleaved PCM
+  // but the engine's planar copy made by planarize_kernel -- one fp32 timeline
+  // (history ++ new frames) per channel, in_plane_stride bytes apart, in_fmt = f32.
+  int in_planar;
+  long long in_plane_stride;
+  // fused path with groups narrower than a frame (cg < channels): the kernel stops after
+  // the staging planes (ext_epilogue = 1) and interleave_*_kernel turns each chunk of
+  // work items (whole (stream, block) pairs: items run group-fastest) into PCM frames.
+  int ext_epilogue;
 };
 
 }  // namespace miups

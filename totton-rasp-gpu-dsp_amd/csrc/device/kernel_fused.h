@@ -169,6 +169,18 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
   BlockIo b;
   const long long ib = pcm_bytes(io.in_fmt);
   const long long f0 = static_cast<long long>(blk) * g.Bc - g.Oc;
+  if (io.in_planar) {
+    // planar fp32 timeline: index hist_frames + f holds frame f of this call
+    b.in_step = 4;
+    b.pin = static_cast<const char *>(io.in) + s * io.in_stream_stride + c * io.in_plane_stride +
+            (g.hist_frames + f0) * 4;
+    b.phist = b.pin;
+    b.n_hist = 0;
+    b.Oc = g.Oc;
+    b.chan = 0;
+    b.vec_mode = (reinterpret_cast<unsigned long long>(b.pin) & 7) == 0 ? 1 : 0;
+    return b;
+  }
   b.in_step = static_cast<int>(ib * io.channels);
   b.pin = static_cast<const char *>(io.in) + s * io.in_stream_stride + (f0 * io.channels + c) * ib;
   b.phist = static_cast<const char *>(io.hist) + s * io.hist_stream_stride +
@@ -925,9 +937,10 @@ struct FusedKernel {
   static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
-    // hardware ids b and b+8 share an L2. Map them to CONSECUTIVE work items:
-    // consecutive blocks of one stream overlap in (taps-1)/L input frames, and an
-    // XCD then finds that history (and its neighbours' new input) in its own L2.
+    // hardware ids b and b+8 share an L2. Map them to CONSECUTIVE work items: with
+    // whole-frame groups those are consecutive blocks of one stream, which overlap in
+    // (taps-1)/L input frames, and an XCD then finds that history (and its neighbours'
+    // new input) in its own L2.
     // Placement only affects speed; any mapping is a bijection onto the items.
     const int nwg = MI_GDIM_X, hw = MI_BID_X;
     const int xq = nwg / 8, xr = nwg % 8, xk = hw % 8;
@@ -938,10 +951,12 @@ struct FusedKernel {
 #endif
     // item = (stream*groups + group) * blocks + block   (block fastest)
     const int item = io.item0 + local;
-    const int sg = item / io.blocks;
-    const int blk = item - sg * io.blocks;
-    const int s = sg / io.groups;
-    const int c0 = (sg - s * io.groups) * io.cg;
+    // item = (stream*blocks + block)*groups + group   (group fastest: a chunk of items
+    // holds whole frames, which the external epilogue needs)
+    const int sb = item / io.groups;
+    const int c0 = (item - sb * io.groups) * io.cg;
+    const int s = sb / io.blocks;
+    const int blk = sb - s * io.blocks;
     float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.B;
     for (int cc = 0; cc < io.cg; ++cc) {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
@@ -952,7 +967,9 @@ struct FusedKernel {
     MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
-    epilogue(g, io, s, c0, blk, scr, lds, tid);
+    if (!io.ext_epilogue) {
+      epilogue(g, io, s, c0, blk, scr, lds, tid);
+    }
     MI_STAMP(129);
   }
 };

@@ -159,6 +159,127 @@ MI_GLOBAL void gen_store_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT y, 
   store_output(g, io, s, c, blk, p, 2 * n + 1, v.y);
 }
 
+// ---- interleaved PCM (history ++ new frames) -> one fp32 timeline per channel ----
+// Pre-pass of the fused path for streams with more than two channels: a frame is then
+// wider than one vector load and a per-channel gather would touch one cache line per
+// sample. A workgroup converts kPlanarTile frames: coalesced reads in memory order, a
+// transpose through LDS ([channel][kPlanarTile + 1] floats), coalesced 256-byte writes
+// per channel. planar[(s*channels + c)*plane_floats + t], t = hist_frames + frame.
+// (reference: the per-channel de-interleave loop, alsa_streamer_main.cpp:315-321)
+constexpr int kPlanarTile = 64;
+MI_GLOBAL void planarize_kernel(Geometry g, IoDesc io, float *MI_RESTRICT planar, long long plane_floats,
+                                long long total_frames, int tiles_per_stream) {
+  MI_DYN_SHARED(float, tile);
+  const int s = static_cast<int>(MI_BID_X) / tiles_per_stream;
+  const long long t0 = static_cast<long long>(static_cast<int>(MI_BID_X) - s * tiles_per_stream) * kPlanarTile;
+  const int C = io.channels, n = kPlanarTile * C;
+  const char *hist = static_cast<const char *>(io.hist) + s * io.hist_stream_stride;
+  const char *in = static_cast<const char *>(io.in) + s * io.in_stream_stride;
+  for (int e = MI_TID_X; e < n; e += MI_BDIM_X) {
+    const int f = e / C, c = e - f * C;
+    const long long t = t0 + f;
+    if (t < total_frames) {
+      const float v = t < g.hist_frames ? pcm_load(hist, io.in_fmt, t * C + c)
+                                        : pcm_load(in, io.in_fmt, (t - g.hist_frames) * C + c);
+      tile[c * (kPlanarTile + 1) + f] = v;
+    }
+  }
+  MI_SYNC();
+  for (int e = MI_TID_X; e < n; e += MI_BDIM_X) {
+    const int c = e / kPlanarTile, f = e - c * kPlanarTile;
+    const long long t = t0 + f;
+    if (t < total_frames) {
+      planar[(static_cast<long long>(s) * C + c) * plane_floats + t] = tile[c * (kPlanarTile + 1) + f];
+    }
+  }
+}
+
+// ---- staging planes of a chunk of (stream, block) pairs -> interleaved PCM frames ----
+// planes[((jb*C + c)*P + p)*Bc + i] = y_p[Oc + i] of channel c of the chunk's jb-th
+// (stream, block) pair sb0 + jb; output frame blk*B + i*P + p, channel c (reference:
+// interleave + ConvertFloatToPcm, alsa_streamer_main.cpp:327-329,550-552).
+// For one i the P*C values (p-major, channel-minor) are R = P*C consecutive output samples.
+//
+// Vector form (4-byte output, R % 4 == 0, Bc % 4 == 0, 16-byte aligned rows): a unit is 4
+// consecutive i of the 4 planes that make one 16-byte run; 4 x 16-byte loads, a 4x4
+// transpose in registers, 4 x 16-byte stores. Lanes run over the R/4 runs of an i first:
+// every store instruction writes R*4 contiguous bytes per i.
+template <int FMT>
+MI_GLOBAL void interleave_quad_kernel(Geometry g, IoDesc io, const float *MI_RESTRICT planes, int sb0, int nb,
+                                      int wgs_per_pair) {
+  constexpr int kUnits = 4;
+  const int jb = static_cast<int>(MI_BID_X) / wgs_per_pair;
+  if (jb >= nb) {
+    return;
+  }
+  const int wg = static_cast<int>(MI_BID_X) - jb * wgs_per_pair;
+  const int C = io.channels, P = g.P, Rq = (P * C) >> 2;
+  const int units = (g.Bc >> 2) * Rq;
+  const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
+  const float *src = planes + static_cast<long long>(jb) * C * g.B;
+  char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride + static_cast<long long>(blk) * g.B * C * 4;
+  const long long i_step = static_cast<long long>(P) * C * 4;  // bytes from i to i + 1
+  const int base = wg * static_cast<int>(MI_BDIM_X) * kUnits + static_cast<int>(MI_TID_X);
+  f4 v[kUnits][4];
+  MI_UNROLL
+  for (int d = 0; d < kUnits; ++d) {
+    const int u = base + d * static_cast<int>(MI_BDIM_X);
+    if (u < units) {
+      const int iq = u / Rq, r0 = (u - iq * Rq) << 2;
+      MI_UNROLL
+      for (int e = 0; e < 4; ++e) {
+        const int r = r0 + e, p = r / C, c = r - p * C;
+        v[d][e] = *reinterpret_cast<const f4 *>(src + (static_cast<long long>(c) * P + p) * g.Bc + 4 * iq);
+      }
+    }
+  }
+  MI_UNROLL
+  for (int d = 0; d < kUnits; ++d) {
+    const int u = base + d * static_cast<int>(MI_BDIM_X);
+    if (u < units) {
+      const int iq = u / Rq, r0 = (u - iq * Rq) << 2;
+      char *dst = out_blk + static_cast<long long>(4 * iq) * i_step + r0 * 4;
+      const float m[4][4] = {{v[d][0].x, v[d][1].x, v[d][2].x, v[d][3].x},
+                             {v[d][0].y, v[d][1].y, v[d][2].y, v[d][3].y},
+                             {v[d][0].z, v[d][1].z, v[d][2].z, v[d][3].z},
+                             {v[d][0].w, v[d][1].w, v[d][2].w, v[d][3].w}};
+      MI_UNROLL
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (FMT == kF32) {
+          *reinterpret_cast<f4 *>(dst + e * i_step) = f4{m[e][0], m[e][1], m[e][2], m[e][3]};
+        } else {
+          struct alignas(16) I4 {
+            int32_t a, b, c, d;
+          };
+          I4 o;
+          o.a = static_cast<int32_t>(pcm_clamp(m[e][0], 0.9999999f) * 2147483648.0f);
+          o.b = static_cast<int32_t>(pcm_clamp(m[e][1], 0.9999999f) * 2147483648.0f);
+          o.c = static_cast<int32_t>(pcm_clamp(m[e][2], 0.9999999f) * 2147483648.0f);
+          o.d = static_cast<int32_t>(pcm_clamp(m[e][3], 0.9999999f) * 2147483648.0f);
+          *reinterpret_cast<I4 *>(dst + e * i_step) = o;
+        }
+      }
+    }
+  }
+}
+// General form: one output sample per thread, lanes in output order.
+MI_GLOBAL void interleave_scalar_kernel(Geometry g, IoDesc io, const float *MI_RESTRICT planes, int sb0, int nb) {
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  const int C = io.channels;
+  const long long per_pair = static_cast<long long>(g.B) * C;
+  if (gid >= per_pair * nb) {
+    return;
+  }
+  const int jb = static_cast<int>(gid / per_pair);
+  const long long rem = gid - jb * per_pair;
+  const int m = static_cast<int>(rem / C), c = static_cast<int>(rem - static_cast<long long>(m) * C);
+  const int i = m / g.P, p = m - i * g.P;
+  const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
+  const float val = planes[((static_cast<long long>(jb) * C + c) * g.P + p) * g.Bc + i];
+  pcm_store(static_cast<char *>(io.out) + s * io.out_stream_stride, io.out_fmt,
+            (static_cast<long long>(blk) * g.B + m) * C + c, val);
+}
+
 // ---- history carry: new_hist = last hist_frames frames of (hist ++ input) --
 // (reference: overlap_.assign(timeBuffer.end() - overlap, ...), :571-572)
 MI_GLOBAL void update_history_kernel(Geometry g, IoDesc io, void *MI_RESTRICT new_hist, long long total_in_frames) {

@@ -101,8 +101,11 @@ class Engine {
   bool fused_ = false;
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
+  std::size_t wgCapacity_ = 256;   // fused path: workgroups resident on the whole chip at once
   float *scratch_ = nullptr;       // fused path: fp32 staging planes
   std::size_t scratchBytes_ = 0;
+  float *planar_ = nullptr;        // fused path, > 2 channels: per-channel fp32 timelines (planarize_kernel)
+  std::size_t planarBytes_ = 0;
   void *hist_[2] = {nullptr, nullptr};
   int cur_ = 0;
   std::size_t histStride_ = 0;  // bytes per stream

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -182,6 +183,9 @@ bool FusedCovers(const Geometry &g, int channels, int inFmt, int outFmt) {
   return g.S == 1 && g.log2k >= 5 && g.log2k <= 14 && inSpan < (1ll << 31) && outSpan < (1ll << 31);
 }
 
+// planarize_kernel keeps a [channels][kPlanarTile + 1] fp32 tile in LDS (64 KiB default limit)
+constexpr int kMaxPlanarChannels = 240;
+
 }  // namespace
 
 void SetLastError(const std::string &message) { g_lastError = message; }
@@ -327,6 +331,7 @@ Engine::~Engine() {
   (void)hipFree(stageIn_);
   (void)hipFree(stageOut_);
   (void)hipFree(scratch_);
+  (void)hipFree(planar_);
   for (void *e : evStart_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -363,14 +368,9 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->outFmt_ = outFmt;
   const Geometry &g = e->filter_->geometry();
   e->fused_ = e->filter_->hasFused() && FusedCovers(g, channels, inFmt, outFmt);
-  // channel group per workgroup is chosen per call (PickChannelGroup); start with the widest
+  // channels per workgroup are chosen per call (PickChannelGroup)
   e->cg_ = 1;
-  for (int d = 1; d <= 8 && d <= channels; ++d) {
-    if (channels % d == 0) {
-      e->cg_ = d;
-    }
-  }
-  e->groups_ = channels / e->cg_;
+  e->groups_ = channels;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->filter_->device()) != hipSuccess || cus <= 0) {
     cus = 256;
@@ -432,31 +432,19 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
   return true;
 }
 
-// Channels per workgroup for this call. Wider groups write longer contiguous runs
-// per frame (whole 32-byte sectors from 8 four-byte channels) but mean fewer
-// workgroups; a group is only narrowed while the launch would otherwise leave CUs
-// without a resident workgroup, and never below a 16-byte run.
+// Channels per workgroup for this call. A workgroup that owns whole frames (mono,
+// stereo) writes them itself from its staging planes, which are still in cache. Wider
+// frames, and stereo calls too small to give every CU a workgroup, run one channel per
+// workgroup and leave the frames to interleave_*_kernel (ProcessDevice).
 void Engine::PickChannelGroup(std::size_t blocks) {
   const Geometry &g = filter_->geometry();
   const int threads = std::max(g.K / 32, 1);
   const int byLds = std::max(1, (160 * 1024) / std::max(g.K * 8, 1));
   const int byWaves = std::max(1, 8 / std::max(threads / 64, 1));
   const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
-  const int ob = pcm_bytes(outFmt_);
-  int pick = 0, narrowest = 0;
-  for (int d = std::min(8, channels_); d >= 1; --d) {
-    if (channels_ % d != 0 || !(d * ob >= 16 || d == channels_)) {
-      continue;
-    }
-    narrowest = d;
-    if (pick == 0 && blocks * streams_ * static_cast<std::size_t>(channels_ / d) >= capacity) {
-      pick = d;
-    }
-  }
-  cg_ = pick ? pick : std::max(narrowest, 1);
-  if (channels_ % cg_ != 0) {
-    cg_ = 1;
-  }
+  wgCapacity_ = std::max<std::size_t>(capacity, 1);
+  const bool whole = channels_ == 1 || (channels_ == 2 && blocks * streams_ >= capacity);
+  cg_ = whole ? channels_ : 1;
   groups_ = channels_ / cg_;
 }
 
@@ -512,19 +500,30 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
   }
   if (fused_) {
-    // one workgroup per (block, stream, channel group); launches are chunked so
-    // that the fp32 staging planes (cg * B floats per workgroup) stay bounded
+    // one workgroup per (stream, block, channel group); launches are chunked by whole
+    // (stream, block) pairs so that the fp32 staging planes (channels * B floats per
+    // pair) stay bounded. (Measured: keeping a chunk inside the 256 MiB Infinity Cache
+    // gains less than launching fewer, fuller rounds of workgroups -- profiles/r01_summary.md.)
     PickChannelGroup(blocks);
-    const std::size_t wgs = static_cast<std::size_t>(blocks) * streams_ * groups_;
-    const std::size_t perWg = static_cast<std::size_t>(cg_) * g.B * sizeof(float);
-    const std::size_t budget = static_cast<std::size_t>(1024) << 20;
-    const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(wgs, budget / perWg));
-    if (chunk * perWg > scratchBytes_) {
+    const bool ext = cg_ < channels_;
+    const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
+    const std::size_t perPair = static_cast<std::size_t>(channels_) * g.B * sizeof(float);
+    std::size_t budget = static_cast<std::size_t>(1024) << 20;
+    if (const char *mb = std::getenv("MIUPS_EXP_CHUNK_MB")) {  // experiment switch (profiles/)
+      budget = static_cast<std::size_t>(std::max(1, std::atoi(mb))) << 20;
+    }
+    std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / perPair));
+    if (chunk < pairs && chunk * groups_ > wgCapacity_) {
+      // several launches: make each a whole number of full-chip rounds of workgroups
+      const std::size_t wgs = chunk * groups_ - (chunk * groups_) % wgCapacity_;
+      chunk = std::max<std::size_t>(1, wgs / groups_);
+    }
+    if (chunk * perPair > scratchBytes_) {
       (void)hipFree(scratch_);
       scratch_ = nullptr;
       scratchBytes_ = 0;
-      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), chunk * perWg));
-      scratchBytes_ = chunk * perWg;
+      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), chunk * perPair));
+      scratchBytes_ = chunk * perPair;
     }
     io.scratch = scratch_;
     io.cg = cg_;
@@ -533,10 +532,64 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
                      (static_cast<std::size_t>(g.B) * channels_ * 4) % 16 == 0)
                         ? 1
                         : 0;
-    for (std::size_t w0 = 0; w0 < wgs; w0 += chunk) {
-      io.item0 = static_cast<int>(w0);
-      const unsigned n = static_cast<unsigned>(std::min<std::size_t>(chunk, wgs - w0));
-      if (!DispatchFused(g, io, *filter_, n, st, error)) {
+    IoDesc ioF = io;  // what the fused kernel reads (io keeps the caller's buffers for the history carry)
+    if (channels_ > 2 && channels_ <= kMaxPlanarChannels) {
+      // wide frames: de-interleave (history ++ new frames) once, coalesced, instead of
+      // gathering one sample per cache line in every channel's first pass
+      const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
+      const long long planeFloats = (total + 3) / 4 * 4;
+      const std::size_t need = static_cast<std::size_t>(planeFloats) * channels_ * streams_ * sizeof(float);
+      if (need > planarBytes_) {
+        (void)hipFree(planar_);
+        planar_ = nullptr;
+        planarBytes_ = 0;
+        MI_HIP(hipMalloc(reinterpret_cast<void **>(&planar_), need));
+        planarBytes_ = need;
+      }
+      const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
+      const std::size_t lds = static_cast<std::size_t>(channels_) * (kPlanarTile + 1) * sizeof(float);
+      hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, io,
+                         planar_, planeFloats, total, tiles);
+      if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
+        return false;
+      }
+      ioF.in = planar_;
+      ioF.in_fmt = kF32;
+      ioF.in_planar = 1;
+      ioF.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
+      ioF.in_stream_stride = ioF.in_plane_stride * channels_;
+    }
+    ioF.ext_epilogue = ext ? 1 : 0;
+    const bool quad = ioF.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 &&
+                      g.Bc % 4 == 0;
+    for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {
+      const std::size_t np = std::min<std::size_t>(chunk, pairs - p0);
+      ioF.item0 = static_cast<int>(p0 * groups_);
+      if (!DispatchFused(g, ioF, *filter_, static_cast<unsigned>(np * groups_), st, error)) {
+        return false;
+      }
+      if (!ext) {
+        continue;
+      }
+      // staging planes of this chunk -> interleaved PCM frames
+      if (quad) {
+        const int threads = 256, perWg = threads * 4;  // interleave_quad_kernel: kUnits = 4
+        const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels_ / 4);
+        const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
+        const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
+        if (outFmt_ == kF32) {
+          hipLaunchKernelGGL(interleave_quad_kernel<kF32>, grid, dim3(threads), 0, st, g, ioF, scratch_,
+                             static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+        } else {
+          hipLaunchKernelGGL(interleave_quad_kernel<kS32>, grid, dim3(threads), 0, st, g, ioF, scratch_,
+                             static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+        }
+      } else {
+        const long long total = static_cast<long long>(np) * g.B * channels_;
+        hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, st, g, ioF, scratch_,
+                           static_cast<int>(p0), static_cast<int>(np));
+      }
+      if (!HipOk(hipGetLastError(), "interleave kernel", error)) {
         return false;
       }
     }
