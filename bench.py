@@ -293,6 +293,15 @@ def main() -> int:
                      "note": "bytes = units*4B(1+1/L) + 8(N/2+1); duration = hipEvent pair around the "
                              f"{path} kernel(s) on the launching stream, rank 0"},
     }
+    # HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json), when
+    # this run is the workload those passes measured
+    try:
+        rec = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(str(args.config))
+    except (OSError, ValueError):
+        rec = None
+    if rec and (rec["streams"], rec["channels"], rec["blocks"]) == (streams, channels, blocks) and not args.dry_run:
+        result["roofline"]["traffic"] = int(rec["bytes"])
+        result["roofline"]["traffic_source"] = rec["source"] + " (separate rocprofv3 --pmc passes; 2*FETCH_SIZE + WRITE_SIZE)"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             result["cpu_baseline"] = cpu_baseline(fpath, args.cpu_seconds)
