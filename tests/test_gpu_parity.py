@@ -158,6 +158,56 @@ def test_engine_batched_interleaved_matches_oracle(ups, O, gpu, fmt_in, fmt_out)
                 assert np.abs(got - want).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
 
 
+# ---- wide frames: planarize -> one channel per workgroup -> interleave kernels -----
+@pytest.mark.parametrize("fname,channels,streams,fmt_in,fmt_out", [
+    ("filter_48k_16x_80000_min_phase", 8, 1, "s32", "s32"),     # BASELINE config 3 shape: vector interleave
+    ("filter_44k_4x_80000_min_phase", 6, 2, "s24", "s24"),      # 5.1, packed 24-bit both ways: scalar interleave
+    ("filter_44k_4x_80000_min_phase", 3, 1, "s16", "f32"),      # odd channel count
+    ("filter_48k_8x_160000_linear_phase", 32, 1, "s32", "s32"), # BASELINE config 5 shape
+    ("filter_44k_2x_80000_min_phase", 4, 1, "f32", "f32"),      # K = 32768: staged path, wide frame
+])
+def test_wide_frames_match_truth_across_calls(ups, O, gpu, fname, channels, streams, fmt_in, fmt_out):
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    h, taps, fft, block, L = O.read_filter(path)
+    filt = ups.Filter(path, device=gpu)
+    eng = ups.Engine(filt, streams, channels, ups.PCM_NAMES[fmt_in], ups.PCM_NAMES[fmt_out])
+    nin, calls, blocks = eng.in_frames, 2, 2
+    rng = np.random.default_rng(channels)
+    xf = np.clip(rng.standard_normal((calls, streams, blocks * nin, channels)) * 0.05, -1, 1).astype(np.float32)
+    outs, xin = [], []
+    for k in range(calls):  # the second call reads real history (through the planar timelines when channels > 2)
+        raw = xf[k] if fmt_in == "f32" else O.float_to_pcm(xf[k].reshape(-1), fmt_in)
+        xin.append((xf[k].reshape(-1) if fmt_in == "f32" else O.pcm_to_float(raw, fmt_in)).reshape(streams, blocks * nin, channels))
+        out = eng.process_host(raw, blocks)
+        y = out.view(np.float32) if fmt_out == "f32" else O.pcm_to_float(out, fmt_out)
+        outs.append(y.reshape(streams, blocks * block, channels))
+    y = np.concatenate(outs, axis=1)
+    x = np.concatenate(xin, axis=1)
+    lsb = {"f32": 0.0, "s16": 2.0**-15, "s24": 2.0**-23, "s32": 2.0**-31}[fmt_out]
+    for s in range(streams):
+        for c in sorted({0, 1, channels // 2, channels - 1}):
+            truth = O.truth_stream(x[s, :, c], h, L, calls * blocks, block).reshape(-1)
+            assert np.abs(y[s, :, c] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
+
+
+def test_wide_frame_channels_are_independent_and_ordered(ups, gpu):
+    """Every channel of a 12-channel frame carries a different constant: each output channel
+    must converge to its own DC level (catches any channel/phase permutation in the
+    planarize / interleave index maps at full size)."""
+    path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+    filt = ups.Filter(path, device=gpu)
+    cfg = filt.config
+    B, L = cfg["block_size"], cfg["upsample_factor"]
+    channels, blocks = 12, 4
+    eng = ups.Engine(filt, 1, channels, ups.PCM_F32, ups.PCM_F32)
+    h = np.fromfile(cfg["coefficients_path"], "<f4").astype(np.float64)
+    levels = (np.arange(channels) + 1) / 64.0
+    x = np.broadcast_to(levels.astype(np.float32), (blocks * eng.in_frames, channels)).copy()
+    y = eng.process_host(x, blocks).view(np.float32).reshape(blocks * B, channels)
+    want = levels * h.sum() / L
+    assert np.abs(y[-1000:].mean(axis=0) - want).max() <= 1e-5
+
+
 def test_history_carries_across_calls_and_reset(ups, O, gpu):
     path = ROOT / "data" / "coefficients" / "filter_48k_16x_80000_min_phase.json"
     filt = ups.Filter(path, device=gpu)
