@@ -126,7 +126,29 @@ void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsign
   miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K>(g, io, ft); });
 }
 
+template <int LOG2K>
+void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
+  using Cfg = FusedCfg<LOG2K>;
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb};
+  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
+}
+
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
+  if (t.fusedSplit) {  // two half-length transforms per block transform
+    switch (g.log2k - 1) {
+      case 5: EmuFusedSplit<5>(g, io, t, items); return true;
+      case 6: EmuFusedSplit<6>(g, io, t, items); return true;
+      case 7: EmuFusedSplit<7>(g, io, t, items); return true;
+      case 8: EmuFusedSplit<8>(g, io, t, items); return true;
+      case 9: EmuFusedSplit<9>(g, io, t, items); return true;
+      case 10: EmuFusedSplit<10>(g, io, t, items); return true;
+      case 11: EmuFusedSplit<11>(g, io, t, items); return true;
+      case 12: EmuFusedSplit<12>(g, io, t, items); return true;
+      case 13: EmuFusedSplit<13>(g, io, t, items); return true;
+      case 14: EmuFusedSplit<14>(g, io, t, items); return true;
+      default: return false;
+    }
+  }
   switch (g.log2k) {
     case 5: EmuFused<5>(g, io, t, items); return true;
     case 6: EmuFused<6>(g, io, t, items); return true;
@@ -155,7 +177,10 @@ int main(int argc, char **argv) {
     return 2;
   }
   const std::string json = argv[1];
-  const int flags = std::atoi(argv[2]);
+  int flags = std::atoi(argv[2]);
+  if (std::getenv("EMU_SPLIT")) {  // tests: the split layout at sizes the emulation can run
+    flags |= kLoadInternalForceSplit;
+  }
   const int streams = std::atoi(argv[3]), channels = std::atoi(argv[4]);
   const int inFmt = std::atoi(argv[5]), outFmt = std::atoi(argv[6]);
   const int blocks = std::atoi(argv[7]), calls = std::atoi(argv[8]);
@@ -174,7 +199,11 @@ int main(int argc, char **argv) {
     return 1;
   }
   const Geometry g = t.geo;
-  const bool fusedOk = g.S == 1 && g.log2k >= 5 && g.log2k <= 14;
+  const bool fusedOk = t.hasFused;
+  if (std::getenv("EMU_SPLIT") && !t.fusedSplit) {
+    std::cerr << "split layout not available for this geometry\n";
+    return 3;
+  }
   const bool fused = path == "fused" ? true : (path == "staged" ? false : fusedOk);
   if (fused && !fusedOk) {
     std::cerr << "fused path does not cover this geometry\n";
@@ -220,7 +249,7 @@ int main(int argc, char **argv) {
         }
       }
       // EMU_INKERNEL=1: keep the in-kernel epilogue for groups narrower than a frame
-      const bool ext = cg < channels && !std::getenv("EMU_INKERNEL");
+      const bool ext = t.fusedSplit || (cg < channels && !std::getenv("EMU_INKERNEL"));
       const unsigned groups = static_cast<unsigned>(channels / cg);
       const unsigned pairs = static_cast<unsigned>(blocks) * streams;
       const unsigned chunk = pairs > 1 ? (pairs + 1) / 2 : pairs;  // exercise the chunked launch (item0 > 0)
@@ -249,6 +278,7 @@ int main(int argc, char **argv) {
         ioF.in_stream_stride = ioF.in_plane_stride * channels;
       }
       ioF.ext_epilogue = ext ? 1 : 0;
+      ioF.split_planes = t.fusedSplit ? 1 : 0;
       const bool quad = ioF.out_vec_ok && (outFmt == kF32 || outFmt == kS32) && (g.P * channels) % 4 == 0 && g.Bc % 4 == 0;
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);

@@ -210,6 +210,41 @@ def test_emulated_wide_epilogue(emu, O, make_filter, tmp_path, monkeypatch, fft,
         assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + (0 if out_fmt == "f32" else 2.0**-31)
 
 
+@pytest.mark.parametrize("fft,taps,L,streams,channels,in_fmt,out_fmt", [
+    (128, 29, 1, 1, 1, "f32", "f32"),      # K = 64 -> half length 32: one thread (the self-mirrored sets only)
+    (256, 57, 2, 1, 2, "f32", "f32"),      # half length 32, two phases
+    (512, 129, 1, 1, 1, "f32", "f32"),     # half length 128
+    (1024, 257, 2, 2, 2, "s32", "s32"),    # half length 128, stereo vector loads
+    (4096, 1025, 2, 1, 3, "s16", "s24"),   # half length 512 (radices 2,16,16), planar input, scalar interleave
+    (8192, 2049, 4, 1, 1, "f32", "f32"),   # half length 512, four phases
+    (16384, 4097, 2, 1, 2, "s32", "f32"),  # half length 2048 (radices 8,16,16)
+    (16384, 4097, 1, 1, 1, "f32", "s32"),  # half length 4096 (radices 16,16,16)
+])
+def test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, streams, channels, in_fmt, out_fmt):
+    """fused_split_kernel: the block transform is twice the LDS transform length (the product
+    uses it for K = 32768, the 2x filters); forced here at small sizes, two calls."""
+    monkeypatch.setenv("EMU_SPLIT", "1")
+    rng = np.random.default_rng(fft + L)
+    h = (rng.standard_normal(taps) * 0.01).astype(np.float32)  # keeps the PCM outputs inside [-1, 1)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks, calls = block // L, 2, 2
+    xf = np.clip(rng.standard_normal((calls, streams, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    if in_fmt == "f32":
+        raw, xin = xf.tobytes(), xf
+    else:
+        raw = O.float_to_pcm(xf.reshape(-1), in_fmt).tobytes()
+        xin = O.pcm_to_float(np.frombuffer(raw, np.uint8), in_fmt).reshape(xf.shape)
+    out = run_emu(emu, tmp_path, p, raw, streams, channels, blocks, calls, "fused", in_fmt, out_fmt)
+    y = np.frombuffer(out, np.float32) if out_fmt == "f32" else O.pcm_to_float(np.frombuffer(out, np.uint8), out_fmt)
+    y = y.reshape(calls, streams, blocks * block, channels)
+    lsb = {"f32": 0.0, "s16": 2.0**-15, "s24": 2.0**-23, "s32": 2.0**-31}[out_fmt]
+    for s in range(streams):
+        for c in range(channels):
+            truth = O.truth_stream(xin[:, s, :, c].reshape(-1), h, L, calls * blocks, block).reshape(-1)
+            assert np.abs(y[:, s, :, c].reshape(-1) - truth).max() <= 1e-5 * np.abs(truth).max() + lsb
+
+
 def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
     """44k 4x shipped filter, one stereo block through both kernel families."""
     path = ROOT / "tests" / "golden" / "filters" / "filter_44k_4x_80000_min_phase.json"

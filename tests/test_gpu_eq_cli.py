@@ -67,10 +67,15 @@ def test_eq_folded_into_filter_spectrum(ups, O, gpu, fname, fs):
 
 
 @pytest.mark.gpu
-def test_staged_and_fused_paths_agree_at_full_size(ups, O, gpu):
-    """2x filter -> K = 32768: the any-size staged path; 4x -> fused. Same truth bar."""
-    for fname, path_name in [("filter_44k_2x_80000_min_phase.json", "staged"), ("filter_44k_4x_80000_min_phase.json", "fused")]:
-        path = ROOT / "data" / "coefficients" / fname
+def test_staged_and_fused_paths_agree_at_full_size(ups, O, gpu, make_filter):
+    """2x filter -> K = 32768: the split fused kernel (two 16384-point halves); 4x -> fused;
+    the same 2x geometry with a history length that is not a multiple of 4 -> the any-size
+    staged path. Same truth bar for all."""
+    h2 = np.fromfile(ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.bin", "<f4")
+    odd = make_filter(np.concatenate([h2, np.zeros(2, np.float32)]), 131072, 131072 - 80002, 2, name="odd2x")
+    for path, path_name in [(ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.json", "fused"),
+                            (ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json", "fused"),
+                            (odd, "staged")]:
         h, taps, fft, block, L = O.read_filter(path)
         filt = ups.Filter(path, device=gpu)
         eng = ups.Engine(filt, 2, 2, ups.PCM_F32, ups.PCM_F32)

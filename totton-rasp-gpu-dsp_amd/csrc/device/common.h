@@ -80,6 +80,7 @@ MI_DEVICE cf cmulc(cf a, cf b) {
 }
 MI_DEVICE cf cconj(cf a) { return mk(a.x, -a.y); }
 MI_DEVICE cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+MI_DEVICE cf cneg(cf a) { return mk(-a.x, -a.y); }
 // j*a and -j*a
 MI_DEVICE cf cmulj(cf a) { return mk(-a.y, a.x); }
 MI_DEVICE cf cmulnj(cf a) { return mk(a.y, -a.x); }
@@ -174,6 +175,9 @@ struct IoDesc {
   // the staging planes (ext_epilogue = 1) and interleave_*_kernel turns each chunk of
   // work items (whole (stream, block) pairs: items run group-fastest) into PCM frames.
   int ext_epilogue;
+  // split form (fused_split_kernel): a staging plane holds the (y[4m], y[4m+1]) pairs in its
+  // first half and the (y[4m+2], y[4m+3]) pairs in its second half (m >= Oc/4, Oc % 4 == 0)
+  int split_planes;
 };
 
 }  // namespace miups

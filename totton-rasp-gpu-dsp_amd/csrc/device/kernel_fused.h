@@ -113,6 +113,45 @@ MI_DEVICE cf w32(int t) {
   return mk(c[t], -s[t]);
 }
 
+// exp(-2*pi*i*t/64), t = 0..16 (split form: M = 64 J)
+MI_DEVICE cf w64(int t) {
+  constexpr float c[17] = {1.0f,
+                           0.99518472667219692873f,
+                           0.98078528040323043058f,
+                           0.95694033573220882438f,
+                           0.92387953251128673848f,
+                           0.88192126434835504956f,
+                           0.83146961230254523567f,
+                           0.77301045336273699338f,
+                           0.70710678118654752440f,
+                           0.63439328416364548779f,
+                           0.55557023301960228867f,
+                           0.47139673682599780857f,
+                           0.38268343236508983729f,
+                           0.29028467725446233105f,
+                           0.19509032201612833135f,
+                           0.09801714032956077016f,
+                           0.0f};
+  constexpr float s[17] = {0.0f,
+                           0.09801714032956060363f,
+                           0.19509032201612824808f,
+                           0.29028467725446233105f,
+                           0.38268343236508978178f,
+                           0.47139673682599764204f,
+                           0.55557023301960217765f,
+                           0.63439328416364548779f,
+                           0.70710678118654752440f,
+                           0.77301045336273699338f,
+                           0.83146961230254523567f,
+                           0.88192126434835493853f,
+                           0.92387953251128673848f,
+                           0.95694033573220893540f,
+                           0.98078528040323043058f,
+                           0.99518472667219681771f,
+                           1.0f};
+  return mk(c[t], -s[t]);
+}
+
 // ---- mirror-pair algebra (see gen_multiply_kernel for the per-bin form) ---
 //   xa = (u+v) - jW(u-v), xb = (u+v) + jW(u-v),  v = conj(zm)
 MI_DEVICE void pair_split(cf u, cf zm, cf W, cf &xa, cf &xb) {
@@ -163,6 +202,9 @@ struct BlockIo {
   // consecutive 16-byte words: full cache lines) and the channel is picked from it.
   int vec_mode;
   int chan;
+  // split form (K = 2 * the LDS transform length): the transform in flight takes the complex
+  // words 2n + half, i.e. compact samples 4n + noff, 4n + noff + 1 (noff = 0 or 2)
+  int noff;
 };
 
 MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int c, int blk) {
@@ -178,6 +220,7 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
     b.n_hist = 0;
     b.Oc = g.Oc;
     b.chan = 0;
+    b.noff = 0;
     b.vec_mode = (reinterpret_cast<unsigned long long>(b.pin) & 7) == 0 ? 1 : 0;
     return b;
   }
@@ -188,6 +231,7 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
   b.n_hist = f0 >= 0 ? 0 : (-f0 > g.M ? g.M : static_cast<int>(-f0));
   b.Oc = g.Oc;
   b.chan = c;
+  b.noff = 0;
   b.vec_mode = 0;
   if (b.n_hist == 0 && (io.in_fmt == kS32 || io.in_fmt == kF32)) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(b.pin);
@@ -298,11 +342,12 @@ struct FusedKernel {
   // kHist = false: the whole block lies in `in` (true for all but the first
   // blocks of a call), one uniform base + 32-bit offsets.
   // MODE: BlockIo::vec_mode (1 and 2 imply !kHist and a 4-byte format)
-  template <int FMT, int R, bool kHist, int MODE>
+  // SP: split form, word q of this transform is complex word 2q + noff/2 of the block
+  template <int FMT, int R, bool kHist, int MODE, int SP = 0>
   static MI_DEVICE void global_read(const BlockIo &b, int q, cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
-      const int n = 2 * (q + t * (K / R));
+      const int n = SP ? 4 * (q + t * (K / R)) + b.noff : 2 * (q + t * (K / R));
       if constexpr (MODE == 1) {
         struct alignas(8) W2 {
           int32_t a, b;
@@ -370,7 +415,7 @@ struct FusedKernel {
 
   // ================= forward (decimation in frequency) ======================
   // pass 0 from HBM: y_u = DFT_R(x)_u * W_K^(u*q), written to q + u*K/R
-  template <int FMT, bool kHist, int MODE>
+  template <int FMT, bool kHist, int MODE, int SP = 0>
   static MI_DEVICE void fwd_first(const BlockIo &b, cf *lds, const cf *tw, int tid) {
     // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all butterflies
     const cf w0 = load_tw<LOG2K>(tw, tid);
@@ -380,7 +425,7 @@ struct FusedKernel {
       cf raw[32 / R0][R0];
       MI_UNROLL
       for (int i = 0; i < 32 / R0; ++i) {
-        global_read<FMT, R0, kHist, MODE>(b, tid + i * T, raw[i]);
+        global_read<FMT, R0, kHist, MODE, SP>(b, tid + i * T, raw[i]);
       }
       MI_UNROLL
       for (int i = 0; i < 32 / R0; ++i) {
@@ -391,8 +436,8 @@ struct FusedKernel {
       }
     } else {
       cf A[16], B[16];
-      global_read<FMT, 16, kHist, MODE>(b, tid, A);
-      global_read<FMT, 16, kHist, MODE>(b, tid + T, B);
+      global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
+      global_read<FMT, 16, kHist, MODE, SP>(b, tid + T, B);
       dft16<-1>(A);
       apply_twiddles_out<-1, 16>(A, w0);
       lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
@@ -402,22 +447,22 @@ struct FusedKernel {
       lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
     }
   }
-  template <int FMT>
+  template <int FMT, int SP = 0>
   static MI_DEVICE void fwd_first_fmt(const BlockIo &b, cf *lds, const cf *tw, int tid) {
     if constexpr (FMT == kS32 || FMT == kF32) {
       if (b.vec_mode == 2) {
-        fwd_first<FMT, false, 2>(b, lds, tw, tid);
+        fwd_first<FMT, false, 2, SP>(b, lds, tw, tid);
         return;
       }
       if (b.vec_mode == 1) {
-        fwd_first<FMT, false, 1>(b, lds, tw, tid);
+        fwd_first<FMT, false, 1, SP>(b, lds, tw, tid);
         return;
       }
     }
     if (b.n_hist == 0) {
-      fwd_first<FMT, false, 0>(b, lds, tw, tid);
+      fwd_first<FMT, false, 0, SP>(b, lds, tw, tid);
     } else {
-      fwd_first<FMT, true, 0>(b, lds, tw, tid);
+      fwd_first<FMT, true, 0, SP>(b, lds, tw, tid);
     }
   }
 
@@ -558,6 +603,122 @@ struct FusedKernel {
       MI_UNROLL
       for (int t = 0; t < 8; ++t) {
         pair_split(B[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wb, w32(t)), Xa[9 + t], Xb[9 + t]);
+      }
+    }
+  }
+
+  // ================= split form: block transform length 2K (K = this LDS length) ===========
+  // The 2K-point transform Z of the block's complex words z[n] is done as two K-point
+  // transforms through the same LDS buffer, E of the even words and O of the odd words,
+  // joined by one radix-2 stage in registers (w = W_2K^k):
+  //     Z[k] = E[k] + w O[k],   Z[k+K] = E[k] - w O[k]                       (forward, DIT)
+  //     A'[k] = Z'[k] + Z'[k+K],  B'[k] = (Z'[k] - Z'[k+K]) conj(w)          (inverse, DIF)
+  //     z'[2n] = IFFT_K(A')[n],   z'[2n+1] = IFFT_K(B')[n]
+  // The K-point mirror pair (k, K-k) a thread owns closes under all of it: it carries the
+  // two 2K-point mirror pairs (k, 2K-k) and (K-k, K+k), whose untangle twiddles are
+  // W1 = W_4K^k and W2 = W_4K^(K-k) = -j conj(W1), and w = W1^2, W_2K^(K-k) = -conj(w).
+  // X1*/X2* hold the untangled spectrum of pair 1 / pair 2 (generic thread: 16 slots each).
+  //
+  // Thread 0 (self-mirrored sets): 33 slots in X1* --
+  //   0: bin 0 (with Nyquist 2K)   1: bin K (its own mirror, W = -j)
+  //   2+2(t-1)+j, t = 1..7: pairs of k = t*J (j = 0: (k, 2K-k), j = 1: (K-k, K+k))
+  //   16: k = K/2 (one pair: (K/2, 3K/2))
+  //   17+2t+j, t = 0..7: pairs of k = J/2 + t*J
+  static MI_DEVICE void quad_split(cf Ek, cf Em, cf Ok, cf Om, cf W1, cf &x1a, cf &x1b, cf &x2a, cf &x2b) {
+    const cf w = cmul(W1, W1);
+    const cf wo = cmul(w, Ok), co = cmulc(Om, w);  // w O[k], conj(w) O[K-k]
+    const cf Zk = cadd(Ek, wo), ZkK = csub(Ek, wo);  // Z[k], Z[k+K]
+    const cf Zm = csub(Em, co), ZmK = cadd(Em, co);  // Z[K-k], Z[2K-k]
+    pair_split(Zk, ZmK, W1, x1a, x1b);
+    pair_split(Zm, ZkK, cneg(cmulj(cconj(W1))), x2a, x2b);
+  }
+  // H = 0: A'[k], A'[K-k]; H = 1: B'[k], B'[K-k]
+  template <int H>
+  static MI_DEVICE void quad_phase(cf x1a, cf x1b, cf x2a, cf x2b, cf W1, f4 g1, f4 g2, cf &ok, cf &om) {
+    cf zk1, zkm1, zk2, zkm2;
+    pair_phase(x1a, x1b, W1, g1, zk1, zkm1);                        // Z'[k], Z'[2K-k]
+    pair_phase(x2a, x2b, cneg(cmulj(cconj(W1))), g2, zk2, zkm2);    // Z'[K-k], Z'[K+k]
+    if constexpr (H == 0) {
+      ok = cadd(zk1, zkm2);
+      om = cadd(zk2, zkm1);
+    } else {
+      const cf w = cmul(W1, W1);
+      ok = cmulc(csub(zk1, zkm2), w);
+      om = cneg(cmul(csub(zk2, zkm1), w));
+    }
+  }
+  template <bool kSelf>
+  static MI_DEVICE void split_spectrum2(const cf *EA, const cf *EB, const cf *OA, const cf *OB, cf Wa, cf Wb, cf *X1a,
+                                        cf *X1b, cf *X2a, cf *X2b) {
+    if constexpr (!kSelf) {
+      MI_UNROLL
+      for (int t = 0; t < 16; ++t) {
+        quad_split(EA[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OA[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
+                   cmul(Wa, w64(t)), X1a[t], X1b[t], X2a[t], X2b[t]);
+      }
+    } else {
+      // thread 0's 33 slots share the generic threads' registers: 0..15 -> X1*, 16..31 -> X2*, 32 -> X1*[16]
+      auto SA = [&](int s) -> cf & { return s < 16 ? X1a[s] : (s < 32 ? X2a[s - 16] : X1a[16]); };
+      auto SB = [&](int s) -> cf & { return s < 16 ? X1b[s] : (s < 32 ? X2b[s - 16] : X1b[16]); };
+      {
+        const cf E0 = EA[out_pos<16>(0)], O0 = OA[out_pos<16>(0)];
+        const cf Z0 = cadd(E0, O0), ZK = csub(E0, O0);
+        pair_split(Z0, Z0, mk(1.0f, 0.0f), SA(0), SB(0));
+        pair_split(ZK, ZK, mk(0.0f, -1.0f), SA(1), SB(1));
+      }
+      MI_UNROLL
+      for (int t = 1; t <= 7; ++t) {
+        const int s = 2 + 2 * (t - 1);
+        quad_split(EA[out_pos<16>(t)], EA[out_pos<16>(16 - t)], OA[out_pos<16>(t)], OA[out_pos<16>(16 - t)], w64(t),
+                   SA(s), SB(s), SA(s + 1), SB(s + 1));
+      }
+      {
+        // k = K/2: w = -j; the pair (K/2, 3K/2)
+        const cf E8 = EA[out_pos<16>(8)], O8 = OA[out_pos<16>(8)];
+        const cf wo = cneg(cmulj(O8));
+        pair_split(cadd(E8, wo), csub(E8, wo), w64(8), SA(16), SB(16));
+      }
+      MI_UNROLL
+      for (int t = 0; t < 8; ++t) {
+        const int s = 17 + 2 * t;
+        quad_split(EB[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OB[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
+                   cmul(Wb, w64(t)), SA(s), SB(s), SA(s + 1), SB(s + 1));
+      }
+    }
+  }
+  // gt: this phase's [2][16][T] table (generic threads), g0: this phase's [33] (thread 0)
+  template <bool kSelf, int H>
+  static MI_DEVICE void phase_inputs2(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, cf Wa, cf Wb,
+                                      const f4 *MI_RESTRICT gt, const f4 *MI_RESTRICT g0, cf *A, cf *B) {
+    if constexpr (!kSelf) {
+      const f4 *pg = gt + tid;
+      MI_UNROLL
+      for (int t = 0; t < 16; ++t) {
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], A[t], B[15 - t]);
+      }
+    } else {
+      auto SA = [&](int s) -> const cf & { return s < 16 ? X1a[s] : (s < 32 ? X2a[s - 16] : X1a[16]); };
+      auto SB = [&](int s) -> const cf & { return s < 16 ? X1b[s] : (s < 32 ? X2b[s - 16] : X1b[16]); };
+      {
+        cf z0, zK, unused;
+        pair_phase(SA(0), SB(0), mk(1.0f, 0.0f), g0[0], z0, unused);
+        pair_phase(SA(1), SB(1), mk(0.0f, -1.0f), g0[1], zK, unused);
+        A[0] = H == 0 ? cadd(z0, zK) : csub(z0, zK);
+      }
+      MI_UNROLL
+      for (int t = 1; t <= 7; ++t) {
+        const int s = 2 + 2 * (t - 1);
+        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), w64(t), g0[s], g0[s + 1], A[t], A[16 - t]);
+      }
+      {
+        cf zk, zkm;
+        pair_phase(SA(16), SB(16), w64(8), g0[16], zk, zkm);  // Z'[K/2], Z'[3K/2]
+        A[8] = H == 0 ? cadd(zk, zkm) : cmulj(csub(zk, zkm));   // conj(w) = +j
+      }
+      MI_UNROLL
+      for (int t = 0; t < 8; ++t) {
+        const int s = 17 + 2 * t;
+        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), cmul(Wb, w64(t)), g0[s], g0[s + 1], B[t], B[15 - t]);
       }
     }
   }
@@ -933,7 +1094,99 @@ struct FusedKernel {
     }
   }
 
+  // Split form of channel_block (block transform length 2K): two forward transforms (even
+  // and odd complex words), then per phase two inverse transforms whose results are the
+  // even and odd complex words of y_p. Half h of phase p goes to plane + h*Bc/2 as
+  // (y[4m + 2h], y[4m + 2h + 1]) pairs, m >= Oc/4 (the host only takes this path when
+  // Oc % 4 == 0); the interleave kernels read that layout (IoDesc::split_planes).
+  static MI_DEVICE void forward_half(const IoDesc &io, const BlockIo &b, const FusedTables &ft, cf *lds, int tid, cf *A,
+                                     cf *B) {
+    switch (io.in_fmt) {
+      case kS32: fwd_first_fmt<kS32, 1>(b, lds, ft.tw, tid); break;
+      case kF32: fwd_first_fmt<kF32, 1>(b, lds, ft.tw, tid); break;
+      case kS16: fwd_first_fmt<kS16, 1>(b, lds, ft.tw, tid); break;
+      default: fwd_first_fmt<kS24_3LE, 1>(b, lds, ft.tw, tid); break;
+    }
+    MI_SYNC();
+    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    if constexpr (kFirstMidStride >= 256) {
+      fwd_mid<256>(lds, ft.tw, tid);
+      MI_SYNC();
+    }
+    if constexpr (kFirstMidStride >= 16) {
+      fwd_mid<16>(lds, ft.tw, tid);
+      MI_SYNC();
+    }
+    fwd_last(lds, Cfg::block_a(tid), ft.blockB[tid], A, B);
+  }
+  static MI_DEVICE void channel_block_split(const Geometry &g, const IoDesc &io, BlockIo b, float *scr_c,
+                                            const FusedTables &ft, cf *lds, int tid, int cc) {
+    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    const int blkA = Cfg::block_a(tid);
+    const int blkB = ft.blockB[tid];
+    cf X1a[17], X1b[17], X2a[16], X2b[16];
+    const cf Wa = ft.WmT[tid];
+    const cf Wb = ft.Wb;
+    {
+      cf EA[16], EB[16], OA[16], OB[16];
+      b.noff = 0;
+      forward_half(io, b, ft, lds, tid, EA, EB);
+      MI_SYNC();  // every thread's last-pass reads done before the next transform's first pass writes
+      b.noff = 2;
+      int t2 = tid;
+      MI_OPAQUE_VGPR(t2);
+      forward_half(io, b, ft, lds, t2, OA, OB);
+      if (tid == 0) {
+        split_spectrum2<true>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
+      } else {
+        split_spectrum2<false>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
+      }
+    }
+    const int rot = (MI_BID_X >> 3) + cc;
+    for (int it = 0; it < 2 * g.P; ++it) {
+      const int p = ((it >> 1) + rot) % g.P, h = it & 1;
+      const f4 *gt = ft.GT + static_cast<long long>(p) * 32 * T;
+      const f4 *g0 = ft.G0 + p * 33;
+      float *half = scr_c + static_cast<long long>(p) * g.Bc + h * (g.Bc >> 1);
+      cf A[16], B[16];
+      int tl = tid;
+      MI_OPAQUE_VGPR(tl);
+      if (tid == 0) {
+        if (h == 0) {
+          phase_inputs2<true, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+        } else {
+          phase_inputs2<true, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+        }
+      } else {
+        if (h == 0) {
+          phase_inputs2<false, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+        } else {
+          phase_inputs2<false, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+        }
+      }
+      int ba = blkA, bb = blkB;
+      MI_OPAQUE_VGPR(ba);
+      MI_OPAQUE_VGPR(bb);
+      inv_first(lds, ba, bb, A, B);
+      MI_SYNC();
+      if constexpr (kFirstMidStride >= 16) {
+        MI_OPAQUE_VGPR(tl);
+        inv_mid<16>(lds, ft.tw, tl);
+        MI_SYNC();
+      }
+      if constexpr (kFirstMidStride >= 256) {
+        MI_OPAQUE_VGPR(tl);
+        inv_mid<256>(lds, ft.tw, tl);
+        MI_SYNC();
+      }
+      MI_OPAQUE_VGPR(tl);
+      inv_last<true>(half, g.Oc >> 1, lds, ft.tw, tl);
+      MI_SYNC();
+    }
+  }
+
   // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
+  template <bool SPLIT = false>
   static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
@@ -962,12 +1215,16 @@ struct FusedKernel {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
-      channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+      if constexpr (SPLIT) {
+        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+      } else {
+        channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+      }
     }
     MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
-    if (!io.ext_epilogue) {
+    if (!SPLIT && !io.ext_epilogue) {  // the split form always leaves the frames to interleave_*_kernel
       epilogue(g, io, s, c0, blk, scr, lds, tid);
     }
     MI_STAMP(129);
@@ -980,6 +1237,16 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 
                                                                                                       FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
   FusedKernel<LOG2K>::run(g, io, ft, lds);
+}
+
+// Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see
+// FusedKernel::channel_block_split. Same launch shape and LDS as fused_kernel<LOG2K>.
+template <int LOG2K>
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_split_kernel(Geometry g,
+                                                                                                            IoDesc io,
+                                                                                                            FusedTables ft) {
+  MI_DYN_SHARED(cf, lds);
+  FusedKernel<LOG2K>::template run<true>(g, io, ft, lds);
 }
 
 }  // namespace miups

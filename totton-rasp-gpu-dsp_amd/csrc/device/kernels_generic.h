@@ -229,7 +229,15 @@ MI_GLOBAL void interleave_quad_kernel(Geometry g, IoDesc io, const float *MI_RES
       MI_UNROLL
       for (int e = 0; e < 4; ++e) {
         const int r = r0 + e, p = r / C, c = r - p * C;
-        v[d][e] = *reinterpret_cast<const f4 *>(src + (static_cast<long long>(c) * P + p) * g.Bc + 4 * iq);
+        const float *pl = src + (static_cast<long long>(c) * P + p) * g.Bc;
+        if (io.split_planes) {
+          // halves of the split form: (y[4m], y[4m+1]) pairs, then (y[4m+2], y[4m+3]) pairs
+          const cf lo = *reinterpret_cast<const cf *>(pl + 2 * iq);
+          const cf hi = *reinterpret_cast<const cf *>(pl + (g.Bc >> 1) + 2 * iq);
+          v[d][e] = f4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+          v[d][e] = *reinterpret_cast<const f4 *>(pl + 4 * iq);
+        }
       }
     }
   }
@@ -275,7 +283,8 @@ MI_GLOBAL void interleave_scalar_kernel(Geometry g, IoDesc io, const float *MI_R
   const int m = static_cast<int>(rem / C), c = static_cast<int>(rem - static_cast<long long>(m) * C);
   const int i = m / g.P, p = m - i * g.P;
   const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
-  const float val = planes[((static_cast<long long>(jb) * C + c) * g.P + p) * g.Bc + i];
+  const int at = io.split_planes ? ((i & 2) ? (g.Bc >> 1) : 0) + 2 * (i >> 2) + (i & 1) : i;
+  const float val = planes[((static_cast<long long>(jb) * C + c) * g.P + p) * g.Bc + at];
   pcm_store(static_cast<char *>(io.out) + s * io.out_stream_stride, io.out_fmt,
             (static_cast<long long>(blk) * g.B + m) * C + c, val);
 }

@@ -39,6 +39,7 @@ class DeviceFilter {
   const cf *Wm() const { return dWm_; }
   const cf *tw() const { return dtw_; }
   bool hasFused() const { return hasFused_; }
+  bool fusedSplit() const { return fusedSplit_; }  // tables are laid out for fused_split_kernel
   FusedTables fused() const { return FusedTables{dtw_, dWmT_, dBlockB_, dGT_, dG0_, wb_}; }
 
  private:
@@ -53,7 +54,7 @@ class DeviceFilter {
   Geometry geo_{};
   cf *dGs_ = nullptr, *dGc_ = nullptr, *dWm_ = nullptr, *dtw_ = nullptr;
   // fused-kernel layout of the same spectra (FusedTables)
-  bool hasFused_ = false;
+  bool hasFused_ = false, fusedSplit_ = false;
   cf *dWmT_ = nullptr;
   int *dBlockB_ = nullptr;
   f4 *dGT_ = nullptr, *dG0_ = nullptr;

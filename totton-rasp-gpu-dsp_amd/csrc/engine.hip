@@ -155,8 +155,35 @@ bool LaunchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, uns
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
 }
 
+template <int LOG2K>
+bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+                      std::string *error) {
+  using Cfg = FusedCfg<LOG2K>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_split_kernel<LOG2K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
+  return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
+}
+
 bool DispatchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
                    std::string *error) {
+  if (f.fusedSplit()) {
+    // block transform length K = 32768: two 16384-point transforms through the LDS
+    // (the split layout is only built for that size outside the emulation tests)
+    if (g.log2k == 15) {
+      return LaunchFusedSplit<14>(g, io, f, items, st, error);
+    }
+    if (error) {
+      *error = "split fused kernel does not cover this geometry";
+    }
+    return false;
+  }
   switch (g.log2k) {
     case 5: return LaunchFused<5>(g, io, f, items, st, error);
     case 6: return LaunchFused<6>(g, io, f, items, st, error);
@@ -180,7 +207,7 @@ bool DispatchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, u
 bool FusedCovers(const Geometry &g, int channels, int inFmt, int outFmt) {
   const long long inSpan = static_cast<long long>(g.M) * channels * pcm_bytes(inFmt);
   const long long outSpan = static_cast<long long>(g.M) * g.P * channels * pcm_bytes(outFmt);
-  return g.S == 1 && g.log2k >= 5 && g.log2k <= 14 && inSpan < (1ll << 31) && outSpan < (1ll << 31);
+  return g.S == 1 && g.log2k >= 5 && g.log2k <= 15 && inSpan < (1ll << 31) && outSpan < (1ll << 31);
 }
 
 // planarize_kernel keeps a [channels][kPlanarTile + 1] fp32 tile in LDS (64 KiB default limit)
@@ -218,6 +245,7 @@ void DeviceFilter::Free() {
   dBlockB_ = nullptr;
   dGT_ = dG0_ = nullptr;
   hasFused_ = false;
+  fusedSplit_ = false;
 }
 
 std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfig &config, std::vector<float> taps,
@@ -263,6 +291,7 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
     }
     wb_ = t.Wb;
     hasFused_ = true;
+    fusedSplit_ = t.fusedSplit;
   }
   return true;
 }
@@ -438,8 +467,9 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
 // workgroup and leave the frames to interleave_*_kernel (ProcessDevice).
 void Engine::PickChannelGroup(std::size_t blocks) {
   const Geometry &g = filter_->geometry();
-  const int threads = std::max(g.K / 32, 1);
-  const int byLds = std::max(1, (160 * 1024) / std::max(g.K * 8, 1));
+  const int ldsK = filter_->fusedSplit() ? g.K / 2 : g.K;  // transform length held in LDS
+  const int threads = std::max(ldsK / 32, 1);
+  const int byLds = std::max(1, (160 * 1024) / std::max(ldsK * 8, 1));
   const int byWaves = std::max(1, 8 / std::max(threads / 64, 1));
   const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
   wgCapacity_ = std::max<std::size_t>(capacity, 1);
@@ -505,7 +535,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // pair) stay bounded. (Measured: keeping a chunk inside the 256 MiB Infinity Cache
     // gains less than launching fewer, fuller rounds of workgroups -- profiles/r01_summary.md.)
     PickChannelGroup(blocks);
-    const bool ext = cg_ < channels_;
+    const bool split = filter_->fusedSplit();
+    const bool ext = cg_ < channels_ || split;  // the split kernel has no epilogue of its own
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.B * sizeof(float);
     std::size_t budget = static_cast<std::size_t>(1024) << 20;
@@ -560,6 +591,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       ioF.in_stream_stride = ioF.in_plane_stride * channels_;
     }
     ioF.ext_epilogue = ext ? 1 : 0;
+    ioF.split_planes = split ? 1 : 0;
     const bool quad = ioF.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 &&
                       g.Bc % 4 == 0;
     for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {

@@ -71,6 +71,63 @@ void BuildFusedLayout(FilterTables *t) {
   t->hasFused = true;
 }
 
+// Split layout (fused_split_kernel<log2k - 1>, kernel_fused.h "split form"): thread sets of
+// the half-length transform (Kh = K/2, Jh = Kh/16, T = Kh/32); every half-length mirror
+// pair (k, Kh-k) carries the two full-length pairs (k, K-k) and (Kh-k, Kh+k).
+bool BuildFusedSplitLayout(FilterTables *t) {
+  const Geometry &g = t->geo;
+  if (g.S != 1 || g.log2k < 6 || g.log2k > 15 || g.Oc % 4 != 0 || g.Bc % 4 != 0) {
+    return false;
+  }
+  const int lh = g.log2k - 1;
+  const int K = g.K, Kh = K / 2, P = g.P, J = Kh / 16, T = Kh / 32;
+  std::vector<int> blockOfSet(J);
+  for (int b = 0; b < J; ++b) {
+    blockOfSet[FusedSetOfBlock(b, lh)] = b;
+  }
+  t->WmT.assign(T, cf{1.0f, 0.0f});
+  t->blockB.assign(T, 0);
+  t->GT.assign(static_cast<std::size_t>(P) * 32 * T, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->G0.assign(static_cast<std::size_t>(P) * 33, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->Wb = t->Wm[J / 2];
+  auto pair = [&](int p, int k) {
+    const cf gs = t->Gs[static_cast<std::size_t>(p) * K + k];
+    const cf gc = t->Gc[static_cast<std::size_t>(p) * K + k];
+    return f4{gs.x, gs.y, gc.x, gc.y};
+  };
+  t->blockB[0] = blockOfSet[J / 2];
+  for (int tau = 1; tau < T; ++tau) {
+    const int a = FusedSetOfBlock(FusedBlockA(tau, lh), lh);  // 0 < a < J/2
+    t->WmT[tau] = t->Wm[a];
+    t->blockB[tau] = blockOfSet[J - a];
+    for (int p = 0; p < P; ++p) {
+      for (int s = 0; s < 16; ++s) {
+        const int k = a + s * J;
+        t->GT[((static_cast<std::size_t>(p) * 2 + 0) * 16 + s) * T + tau] = pair(p, k);
+        t->GT[((static_cast<std::size_t>(p) * 2 + 1) * 16 + s) * T + tau] = pair(p, Kh - k);
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p) {
+    f4 *g0 = &t->G0[static_cast<std::size_t>(p) * 33];
+    g0[0] = pair(p, 0);
+    g0[1] = pair(p, Kh);
+    for (int s = 1; s <= 7; ++s) {
+      g0[2 + 2 * (s - 1)] = pair(p, s * J);
+      g0[2 + 2 * (s - 1) + 1] = pair(p, Kh - s * J);
+    }
+    g0[16] = pair(p, 8 * J);
+    for (int s = 0; s < 8; ++s) {
+      const int k = J / 2 + s * J;
+      g0[17 + 2 * s] = pair(p, k);
+      g0[17 + 2 * s + 1] = pair(p, Kh - k);
+    }
+  }
+  t->hasFused = true;
+  t->fusedSplit = true;
+  return true;
+}
+
 }  // namespace
 
 int FusedSetOfBlock(int block, int log2k) {
@@ -229,6 +286,10 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
       const double a = -2.0 * pi * static_cast<double>(k) / static_cast<double>(1 << q);
       out->tw[tw_offset(q) + k] = cf{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
     }
+  }
+  out->fusedSplit = false;
+  if (((flags & kLoadInternalForceSplit) || out->geo.log2k == 15) && BuildFusedSplitLayout(out)) {
+    return true;
   }
   BuildFusedLayout(out);
   return true;

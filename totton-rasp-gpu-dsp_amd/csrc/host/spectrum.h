@@ -29,12 +29,20 @@ struct FilterTables {
   // The same spectra in the fused kernel's thread order (FusedTables in
   // device/common.h); empty when the geometry is outside the fused kernel.
   bool hasFused = false;
+  // fusedSplit: the layout is for fused_split_kernel<log2k - 1> (two half-length transforms
+  // per block transform): T = K/64 threads, GT [P][2][16][T], G0 [P][33]. Chosen when
+  // K = 32768 (one size past the LDS) and the history length is a multiple of 4.
+  bool fusedSplit = false;
   std::vector<cf> WmT;      // [T]
   std::vector<int> blockB;  // [T]
   std::vector<f4> GT;       // [P][16][T]
   std::vector<f4> G0;       // [P][17]
   cf Wb{1.0f, 0.0f};
 };
+
+// BuildTables flag for the emulation driver only (tests/emu): build the split layout for
+// any K the split kernel covers, so that it can be checked at small sizes.
+constexpr int kLoadInternalForceSplit = 0x100;
 
 // Frequency layout of the fused kernel's in-place FFT (radices R0,16,..,16,
 // decimation in frequency): after the forward transform LDS block b holds the
