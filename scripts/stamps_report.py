@@ -2,7 +2,7 @@
 """Run a bench workload once with a MIUPS_STAMPS library variant and print the
 per-stage cycle breakdown of the fused kernel (diagnostic; see MI_STAMP).
 
-env: MIUPS_LIB (default lib_ablate/libmi_upsampler_STAMPS.so), STAMPS_CONFIG = 2|3|5,
+env: MIUPS_LIB (default lib_ablate/libmi_upsampler_STAMPS.so), STAMPS_CONFIG = 2|3|4|5,
      STAMPS_BRIEF=1 (aggregate only). Stamp slots cover the LAST two channels and the
      LAST four phases a workgroup processed."""
 import ctypes as C
@@ -21,6 +21,7 @@ import totton_rasp_gpu_dsp_amd as ups  # noqa: E402
 
 CONFIGS = {2: ("filter_44k_4x_80000_min_phase.json", 2, 256, None),
            3: ("filter_48k_16x_80000_min_phase.json", 8, 256, 768000.0),
+           4: ("filter_44k_2x_80000_min_phase.json", 2, 1024, None),   # split kernel: fwd_first..fwd_last = both halves
            5: ("filter_48k_8x_160000_linear_phase.json", 32, 64, 768000.0)}
 fname, channels, blocks, eq_fs = CONFIGS[int(os.environ.get("STAMPS_CONFIG", "2"))]
 filt = ups.Filter(ROOT / "data" / "coefficients" / fname)
@@ -37,6 +38,8 @@ buf = (C.c_ulonglong * n)()
 assert ups.lib.mi_debug_read_stamps(buf, n) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(32, 8, 192).astype(np.int64)
 waves = max(1, min(8, (filt.config["fft_size"] // filt.config["upsample_factor"] // 2 // 32) // 64))
+if filt.config["fft_size"] // filt.config["upsample_factor"] // 2 == 32768:
+    waves = 8  # split kernel: 16384-point transforms
 st = st[:, :waves]
 names = {0: "start", 1: "fwd_first", 2: "sync", 3: "fwd_mid256", 4: "sync", 5: "fwd_mid16", 6: "sync", 7: "fwd_last",
          8: "split"}

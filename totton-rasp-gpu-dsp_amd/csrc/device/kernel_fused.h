@@ -655,6 +655,9 @@ struct FusedKernel {
       for (int t = 0; t < 16; ++t) {
         quad_split(EA[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OA[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
                    cmul(Wa, w64(t)), X1a[t], X1b[t], X2a[t], X2b[t]);
+        if ((t & 3) == 3) {
+          MI_SCHED_FENCE();  // inputs die as outputs are born: keeps the stage near 128 + 32 registers
+        }
       }
     } else {
       // thread 0's 33 slots share the generic threads' registers: 0..15 -> X1*, 16..31 -> X2*, 32 -> X1*[16]
@@ -694,7 +697,16 @@ struct FusedKernel {
       const f4 *pg = gt + tid;
       MI_UNROLL
       for (int t = 0; t < 16; ++t) {
+#if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table loads (wrong results)
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
+                      f4{0.5f, 0.0f, 0.5f, 0.0f}, A[t], B[15 - t]);
+        (void)pg;
+#else
         quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], A[t], B[15 - t]);
+#endif
+        if ((t & 3) == 3) {
+          MI_SCHED_FENCE();  // at most 8 table words in flight: the spectrum already holds 128 registers
+        }
       }
     } else {
       auto SA = [&](int s) -> const cf & { return s < 16 ? X1a[s] : (s < 32 ? X2a[s - 16] : X1a[16]); };
@@ -1119,9 +1131,32 @@ struct FusedKernel {
     }
     fwd_last(lds, Cfg::block_a(tid), ft.blockB[tid], A, B);
   }
+  // One butterfly in flight instead of two: the split form keeps 64 (thread 0: 66) complex
+  // values of untangled spectrum per thread across the inverse passes (twice the plain
+  // kernel's), which leaves room for one radix-16 butterfly's registers, not two.
+  // (Measured alternative: parking half of the spectrum in global memory between uses
+  // made the spectral stage 10x slower -- the parked words fall out of L2.)
+  template <int S>
+  static MI_DEVICE void inv_mid_seq(cf *lds, const cf *tw, int tid) {
+    constexpr int LOG2L = (S == 16) ? 8 : 12;
+    MI_UNROLL
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + i * T;
+      const cf w = load_tw<LOG2L>(tw, q & (S - 1));
+      const Bfly<16, S> bf(q);
+      cf V[16];
+      lds_get<16, S>(lds, bf, V);
+      apply_twiddles<+1, 16>(V, w);
+      dft16<+1>(V);
+      lds_put_dft<16, S>(lds, bf, V);
+      MI_SCHED_FENCE();
+    }
+  }
   static MI_DEVICE void channel_block_split(const Geometry &g, const IoDesc &io, BlockIo b, float *scr_c,
                                             const FusedTables &ft, cf *lds, int tid, int cc) {
     constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
+    (void)sb;
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
     cf X1a[17], X1b[17], X2a[16], X2b[16];
@@ -1130,18 +1165,23 @@ struct FusedKernel {
     {
       cf EA[16], EB[16], OA[16], OB[16];
       b.noff = 0;
+      MI_STAMP(sb + 0);
       forward_half(io, b, ft, lds, tid, EA, EB);
+      MI_STAMP(sb + 1);
       MI_SYNC();  // every thread's last-pass reads done before the next transform's first pass writes
+      MI_STAMP(sb + 2);
       b.noff = 2;
       int t2 = tid;
       MI_OPAQUE_VGPR(t2);
       forward_half(io, b, ft, lds, t2, OA, OB);
+      MI_STAMP(sb + 7);
       if (tid == 0) {
         split_spectrum2<true>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
       } else {
         split_spectrum2<false>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
       }
     }
+    MI_STAMP(sb + 8);
     const int rot = (MI_BID_X >> 3) + cc;
     for (int it = 0; it < 2 * g.P; ++it) {
       const int p = ((it >> 1) + rot) % g.P, h = it & 1;
@@ -1164,24 +1204,35 @@ struct FusedKernel {
           phase_inputs2<false, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
         }
       }
+      const int sp = sb + 9 + 10 * (it & 3);
+      (void)sp;
+      MI_STAMP(sp + 0);
       int ba = blkA, bb = blkB;
       MI_OPAQUE_VGPR(ba);
       MI_OPAQUE_VGPR(bb);
       inv_first(lds, ba, bb, A, B);
+      MI_STAMP(sp + 1);
       MI_SYNC();
+      MI_STAMP(sp + 2);
       if constexpr (kFirstMidStride >= 16) {
         MI_OPAQUE_VGPR(tl);
-        inv_mid<16>(lds, ft.tw, tl);
+        inv_mid_seq<16>(lds, ft.tw, tl);
+        MI_STAMP(sp + 3);
         MI_SYNC();
+        MI_STAMP(sp + 4);
       }
       if constexpr (kFirstMidStride >= 256) {
         MI_OPAQUE_VGPR(tl);
-        inv_mid<256>(lds, ft.tw, tl);
+        inv_mid_seq<256>(lds, ft.tw, tl);
+        MI_STAMP(sp + 5);
         MI_SYNC();
+        MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
       inv_last<true>(half, g.Oc >> 1, lds, ft.tw, tl);
+      MI_STAMP(sp + 7);
       MI_SYNC();
+      MI_STAMP(sp + 8);
     }
   }
 

@@ -257,7 +257,7 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
   f->device_ = device;
   f->config_ = config;
   f->taps_ = std::move(taps);
-  f->flags_ = flags;
+  f->flags_ = flags & kLoadRefCompatSpectrum;  // the only load flag of the public boundary
   if (!f->Rebuild(nullptr, error)) {
     return nullptr;
   }
