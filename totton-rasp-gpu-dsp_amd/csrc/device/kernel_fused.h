@@ -689,21 +689,28 @@ struct FusedKernel {
       }
     }
   }
-  // gt: this phase's [2][16][T] table (generic threads), g0: this phase's [33] (thread 0)
+  // gt: this phase's [2][16][T] table (generic threads), g0: this phase's [33] (thread 0).
+  // The inputs of the first inverse pass for the thread's first block come back in A; those
+  // for its second block go, in natural order, to that block's own LDS words (bB) -- the
+  // block is dead at this point and only this thread touches it before the next barrier,
+  // and the spectrum already holds 128 registers (A and B together would not fit beside it).
   template <bool kSelf, int H>
   static MI_DEVICE void phase_inputs2(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, cf Wa, cf Wb,
-                                      const f4 *MI_RESTRICT gt, const f4 *MI_RESTRICT g0, cf *A, cf *B) {
+                                      const f4 *MI_RESTRICT gt, const f4 *MI_RESTRICT g0, cf *A, cf *lds,
+                                      const Bfly<16, 1> &bB) {
     if constexpr (!kSelf) {
       const f4 *pg = gt + tid;
       MI_UNROLL
       for (int t = 0; t < 16; ++t) {
+        cf om;
 #if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table loads (wrong results)
         quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
-                      f4{0.5f, 0.0f, 0.5f, 0.0f}, A[t], B[15 - t]);
+                      f4{0.5f, 0.0f, 0.5f, 0.0f}, A[t], om);
         (void)pg;
 #else
-        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], A[t], B[15 - t]);
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], A[t], om);
 #endif
+        lds[bB.at(15 - t)] = om;
         if ((t & 3) == 3) {
           MI_SCHED_FENCE();  // at most 8 table words in flight: the spectrum already holds 128 registers
         }
@@ -730,7 +737,10 @@ struct FusedKernel {
       MI_UNROLL
       for (int t = 0; t < 8; ++t) {
         const int s = 17 + 2 * t;
-        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), cmul(Wb, w64(t)), g0[s], g0[s + 1], B[t], B[15 - t]);
+        cf ok, om;
+        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), cmul(Wb, w64(t)), g0[s], g0[s + 1], ok, om);
+        lds[bB.at(t)] = ok;
+        lds[bB.at(15 - t)] = om;
       }
     }
   }
@@ -958,7 +968,12 @@ struct FusedKernel {
       const bool runs4 = (cg % 4 == 0 && io.channels % 4 == 0) || (cg == io.channels && R % 4 == 0);
       const bool fits = static_cast<long long>(R) * 65 * 4 <= static_cast<long long>(K) * 8 && (R * 64) % T == 0;
       const bool wide = pow2 && R > 16 && runs4 && io.out_vec_ok && (io.out_fmt == kF32 || io.out_fmt == kS32);
-      if (wide && g.Bc % 4 == 0 && reinterpret_cast<uintptr_t>(scr) % 16 == 0) {
+#if defined(MIUPS_EXP_QUAD8)  // experiment switch (profiles/): register-transposed form from 8 planes up
+      const bool quad = (wide || (pow2 && R >= 8 && runs4 && io.out_vec_ok && (io.out_fmt == kF32 || io.out_fmt == kS32)));
+#else
+      const bool quad = wide;
+#endif
+      if (quad && g.Bc % 4 == 0 && reinterpret_cast<uintptr_t>(scr) % 16 == 0) {
         if (io.out_fmt == kF32) {
           epilogue_quad<kF32>(g, io, out_blk, scr, tid);
         } else {
@@ -1188,29 +1203,37 @@ struct FusedKernel {
       const f4 *gt = ft.GT + static_cast<long long>(p) * 32 * T;
       const f4 *g0 = ft.G0 + p * 33;
       float *half = scr_c + static_cast<long long>(p) * g.Bc + h * (g.Bc >> 1);
-      cf A[16], B[16];
+      cf A[16];
       int tl = tid;
       MI_OPAQUE_VGPR(tl);
+      int ba = blkA, bb = blkB;
+      MI_OPAQUE_VGPR(ba);
+      MI_OPAQUE_VGPR(bb);
+      const Bfly<16, 1> bfB(bb);
       if (tid == 0) {
         if (h == 0) {
-          phase_inputs2<true, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+          phase_inputs2<true, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
         } else {
-          phase_inputs2<true, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+          phase_inputs2<true, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
         }
       } else {
         if (h == 0) {
-          phase_inputs2<false, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+          phase_inputs2<false, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
         } else {
-          phase_inputs2<false, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, B);
+          phase_inputs2<false, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
         }
       }
       const int sp = sb + 9 + 10 * (it & 3);
       (void)sp;
       MI_STAMP(sp + 0);
-      int ba = blkA, bb = blkB;
-      MI_OPAQUE_VGPR(ba);
-      MI_OPAQUE_VGPR(bb);
-      inv_first(lds, ba, bb, A, B);
+      // first inverse pass (stride 1), one block at a time; the second block's inputs were
+      // left in its own LDS words by phase_inputs2
+      dft16<+1>(A);
+      lds_put_dft<16, 1>(lds, Bfly<16, 1>(ba), A);
+      MI_SCHED_FENCE();
+      lds_get<16, 1>(lds, bfB, A);
+      dft16<+1>(A);
+      lds_put_dft<16, 1>(lds, bfB, A);
       MI_STAMP(sp + 1);
       MI_SYNC();
       MI_STAMP(sp + 2);
