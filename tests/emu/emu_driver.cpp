@@ -122,25 +122,20 @@ cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
 template <int LOG2K>
 void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb};
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr};
   miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K>(g, io, ft); });
 }
 
 template <int LOG2K>
 void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb};
-  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, t.selfW.data()};
+  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
 }
 
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   if (t.fusedSplit) {  // two half-length transforms per block transform
     switch (g.log2k - 1) {
-      case 5: EmuFusedSplit<5>(g, io, t, items); return true;
-      case 6: EmuFusedSplit<6>(g, io, t, items); return true;
-      case 7: EmuFusedSplit<7>(g, io, t, items); return true;
-      case 8: EmuFusedSplit<8>(g, io, t, items); return true;
-      case 9: EmuFusedSplit<9>(g, io, t, items); return true;
       case 10: EmuFusedSplit<10>(g, io, t, items); return true;
       case 11: EmuFusedSplit<11>(g, io, t, items); return true;
       case 12: EmuFusedSplit<12>(g, io, t, items); return true;

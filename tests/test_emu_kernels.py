@@ -211,18 +211,17 @@ def test_emulated_wide_epilogue(emu, O, make_filter, tmp_path, monkeypatch, fft,
 
 
 @pytest.mark.parametrize("fft,taps,L,streams,channels,in_fmt,out_fmt", [
-    (128, 29, 1, 1, 1, "f32", "f32"),      # K = 64 -> half length 32: one thread (the self-mirrored sets only)
-    (256, 57, 2, 1, 2, "f32", "f32"),      # half length 32, two phases
-    (512, 129, 1, 1, 1, "f32", "f32"),     # half length 128
-    (1024, 257, 2, 2, 2, "s32", "s32"),    # half length 128, stereo vector loads
-    (4096, 1025, 2, 1, 3, "s16", "s24"),   # half length 512 (radices 2,16,16), planar input, scalar interleave
-    (8192, 2049, 4, 1, 1, "f32", "f32"),   # half length 512, four phases
-    (16384, 4097, 2, 1, 2, "s32", "f32"),  # half length 2048 (radices 8,16,16)
-    (16384, 4097, 1, 1, 1, "f32", "s32"),  # half length 4096 (radices 16,16,16)
+    (4096, 1025, 1, 1, 1, "f32", "f32"),    # half length 1024 (radices 4,16,16): 32 threads, 17 of them self lanes
+    (8192, 2049, 2, 2, 2, "s32", "s32"),    # half length 1024, two phases, stereo vector loads
+    (16384, 4097, 2, 1, 3, "s16", "s24"),   # half length 2048 (radices 8,16,16), planar input, scalar interleave
+    (16384, 4097, 1, 1, 1, "f32", "s32"),   # half length 4096 (radices 16,16,16)
+    (32768, 8193, 4, 1, 1, "f32", "f32"),   # half length 2048, four phases
+    (32768, 8193, 1, 1, 2, "s32", "f32"),   # half length 8192 (radices 2,16,16,16): 256 threads
 ])
 def test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, streams, channels, in_fmt, out_fmt):
     """fused_split_kernel: the block transform is twice the LDS transform length (the product
-    uses it for K = 32768, the 2x filters); forced here at small sizes, two calls."""
+    uses it for K = 32768, the 2x filters); forced here at the smaller sizes it covers
+    (half length >= 1024), two calls."""
     monkeypatch.setenv("EMU_SPLIT", "1")
     rng = np.random.default_rng(fft + L)
     h = (rng.standard_normal(taps) * 0.01).astype(np.float32)  # keeps the PCM outputs inside [-1, 1)

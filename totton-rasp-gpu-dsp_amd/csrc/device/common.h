@@ -111,6 +111,8 @@ struct FusedTables {
   const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau)
   const f4 *G0;        // [P][17]        thread 0: k = t*J (t = 0..8) then k = J/2 + t*J (t = 0..7)
   cf Wb;               // W_M^(J/2)
+  // split form (fused_split_kernel) instead: GT [P][2][16][T], G0 [P][2][17] (self lanes), and
+  const cf *selfW;     // [17]           W_M^k of self lane l: k = l*J (l <= 8), J/2 + (l-9)*J
 };
 
 // PCM sample formats at the batched boundary. Values mirror include/mi_upsampler.h.

@@ -255,6 +255,7 @@ struct FusedCfg {
   // radix of the pass before the last one: its digit is the low digit of the block index
   static constexpr int RL = (N16 >= 2) ? 16 : R0;
   static constexpr int LDS_BYTES = K * 8;
+  static constexpr int LDS_BYTES_SPLIT = K * 8 + 64 * 8;  // + FusedKernel::kXchWords
   static_assert(LOG2K >= 5 && LOG2K <= 14, "fused kernel covers K = 32 .. 16384");
   // LDS block of the thread's first set in the pairing passes: the tau-th block
   // whose low digit is < RL/2 (exactly the sets S_a with a < J/2)
@@ -617,13 +618,39 @@ struct FusedKernel {
   // The K-point mirror pair (k, K-k) a thread owns closes under all of it: it carries the
   // two 2K-point mirror pairs (k, 2K-k) and (K-k, K+k), whose untangle twiddles are
   // W1 = W_4K^k and W2 = W_4K^(K-k) = -j conj(W1), and w = W1^2, W_2K^(K-k) = -conj(w).
-  // X1*/X2* hold the untangled spectrum of pair 1 / pair 2 (generic thread: 16 slots each).
+  // X1*/X2* hold the untangled spectrum of pair 1 / pair 2 (16 quads per thread).
   //
-  // Thread 0 (self-mirrored sets): 33 slots in X1* --
-  //   0: bin 0 (with Nyquist 2K)   1: bin K (its own mirror, W = -j)
-  //   2+2(t-1)+j, t = 1..7: pairs of k = t*J (j = 0: (k, 2K-k), j = 1: (K-k, K+k))
-  //   16: k = K/2 (one pair: (K/2, 3K/2))
-  //   17+2t+j, t = 0..7: pairs of k = J/2 + t*J
+  // Thread 0 owns the self-mirrored sets S_0 and S_{J/2}. Their 17 mirror pairs are quads of
+  // exactly the same form (k = 0: pairs (0, 2K) and (K, K); k = K/2: both pairs coincide), so
+  // instead of a second code path that would make wave 0 take twice as long as every other
+  // wave at each spectral stage, lanes 0..16 of wave 0 take one of them each as a 17th quad:
+  // thread 0 publishes its 64 transform outputs through 64 extra LDS words (xch), lane l
+  // picks its four, and the results go straight into thread 0's two LDS blocks as the inputs
+  // of its first inverse pass. Lane l <= 8: k = l*J (set S_0); lane l >= 9: k = J/2 + (l-9)*J.
+  struct SelfLane {
+    int srcK, srcM;  // xch words of E[k], E[K-k] (O at +32)
+    int posK, posM;  // LDS words of the first-pass inputs A'[k], A'[K-k] in thread 0's blocks
+  };
+  static MI_DEVICE SelfLane self_lane(int tid, int blkB0) {
+    SelfLane sl;
+    if (tid <= 8) {
+      const Bfly<16, 1> b0(Cfg::block_a(0));
+      sl.srcK = tid;
+      sl.srcM = (16 - tid) & 15;
+      sl.posK = b0.at(tid);
+      sl.posM = b0.at((16 - tid) & 15);
+    } else {
+      const int t = (tid - 9) & 7;
+      const Bfly<16, 1> b1(blkB0);
+      sl.srcK = 16 + t;
+      sl.srcM = 16 + 15 - t;
+      sl.posK = b1.at(t);
+      sl.posM = b1.at(15 - t);
+    }
+    return sl;
+  }
+  static constexpr int kSelfLanes = 17;
+  static constexpr int kXchWords = 64;
   static MI_DEVICE void quad_split(cf Ek, cf Em, cf Ok, cf Om, cf W1, cf &x1a, cf &x1b, cf &x2a, cf &x2b) {
     const cf w = cmul(W1, W1);
     const cf wo = cmul(w, Ok), co = cmulc(Om, w);  // w O[k], conj(w) O[K-k]
@@ -647,101 +674,51 @@ struct FusedKernel {
       om = cneg(cmul(csub(zk2, zkm1), w));
     }
   }
-  template <bool kSelf>
-  static MI_DEVICE void split_spectrum2(const cf *EA, const cf *EB, const cf *OA, const cf *OB, cf Wa, cf Wb, cf *X1a,
-                                        cf *X1b, cf *X2a, cf *X2b) {
-    if constexpr (!kSelf) {
-      MI_UNROLL
-      for (int t = 0; t < 16; ++t) {
-        quad_split(EA[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OA[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
-                   cmul(Wa, w64(t)), X1a[t], X1b[t], X2a[t], X2b[t]);
-        if ((t & 3) == 3) {
-          MI_SCHED_FENCE();  // inputs die as outputs are born: keeps the stage near 128 + 32 registers
-        }
-      }
-    } else {
-      // thread 0's 33 slots share the generic threads' registers: 0..15 -> X1*, 16..31 -> X2*, 32 -> X1*[16]
-      auto SA = [&](int s) -> cf & { return s < 16 ? X1a[s] : (s < 32 ? X2a[s - 16] : X1a[16]); };
-      auto SB = [&](int s) -> cf & { return s < 16 ? X1b[s] : (s < 32 ? X2b[s - 16] : X1b[16]); };
-      {
-        const cf E0 = EA[out_pos<16>(0)], O0 = OA[out_pos<16>(0)];
-        const cf Z0 = cadd(E0, O0), ZK = csub(E0, O0);
-        pair_split(Z0, Z0, mk(1.0f, 0.0f), SA(0), SB(0));
-        pair_split(ZK, ZK, mk(0.0f, -1.0f), SA(1), SB(1));
-      }
-      MI_UNROLL
-      for (int t = 1; t <= 7; ++t) {
-        const int s = 2 + 2 * (t - 1);
-        quad_split(EA[out_pos<16>(t)], EA[out_pos<16>(16 - t)], OA[out_pos<16>(t)], OA[out_pos<16>(16 - t)], w64(t),
-                   SA(s), SB(s), SA(s + 1), SB(s + 1));
-      }
-      {
-        // k = K/2: w = -j; the pair (K/2, 3K/2)
-        const cf E8 = EA[out_pos<16>(8)], O8 = OA[out_pos<16>(8)];
-        const cf wo = cneg(cmulj(O8));
-        pair_split(cadd(E8, wo), csub(E8, wo), w64(8), SA(16), SB(16));
-      }
-      MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        const int s = 17 + 2 * t;
-        quad_split(EB[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OB[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
-                   cmul(Wb, w64(t)), SA(s), SB(s), SA(s + 1), SB(s + 1));
+  static MI_DEVICE void split_spectrum2(const cf *EA, const cf *EB, const cf *OA, const cf *OB, cf Wa, cf *X1a, cf *X1b,
+                                        cf *X2a, cf *X2b) {
+    MI_UNROLL
+    for (int t = 0; t < 16; ++t) {
+      quad_split(EA[out_pos<16>(t)], EB[out_pos<16>(15 - t)], OA[out_pos<16>(t)], OB[out_pos<16>(15 - t)],
+                 cmul(Wa, w64(t)), X1a[t], X1b[t], X2a[t], X2b[t]);
+      if ((t & 3) == 3) {
+        MI_SCHED_FENCE();  // inputs die as outputs are born: keeps the stage near 128 + 32 registers
       }
     }
   }
-  // gt: this phase's [2][16][T] table (generic threads), g0: this phase's [33] (thread 0).
-  // The inputs of the first inverse pass for the thread's first block come back in A; those
-  // for its second block go, in natural order, to that block's own LDS words (bB) -- the
-  // block is dead at this point and only this thread touches it before the next barrier,
-  // and the spectrum already holds 128 registers (A and B together would not fit beside it).
-  template <bool kSelf, int H>
-  static MI_DEVICE void phase_inputs2(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, cf Wa, cf Wb,
-                                      const f4 *MI_RESTRICT gt, const f4 *MI_RESTRICT g0, cf *A, cf *lds,
-                                      const Bfly<16, 1> &bB) {
-    if constexpr (!kSelf) {
-      const f4 *pg = gt + tid;
-      MI_UNROLL
-      for (int t = 0; t < 16; ++t) {
-        cf om;
+  // gt: this phase's [2][16][T] table, g0: this phase's [2][17] table of the self lanes.
+  // The inputs of the first inverse pass go, in natural order, straight to the LDS words of
+  // the thread's own two blocks (bA, bB): the blocks are dead at this point, only this thread
+  // touches them before the next barrier, and the spectrum already holds 128 registers (the
+  // 32 results would not fit beside it). Thread 0 has no quads of its own (its table rows
+  // are zero and its stores are masked); both its blocks are filled by the self lanes.
+  template <int H>
+  static MI_DEVICE void phase_inputs2(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, const cf *Xs,
+                                      cf Wa, cf Ws, const SelfLane &sl, const f4 *MI_RESTRICT gt,
+                                      const f4 *MI_RESTRICT g0, cf *lds, const Bfly<16, 1> &bA, const Bfly<16, 1> &bB) {
+    const f4 *pg = gt + tid;
+    MI_UNROLL
+    for (int t = 0; t < 16; ++t) {
+      cf ok, om;
 #if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table loads (wrong results)
-        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
-                      f4{0.5f, 0.0f, 0.5f, 0.0f}, A[t], om);
-        (void)pg;
+      quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
+                    f4{0.5f, 0.0f, 0.5f, 0.0f}, ok, om);
+      (void)pg;
 #else
-        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], A[t], om);
+      quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], ok, om);
 #endif
-        lds[bB.at(15 - t)] = om;
-        if ((t & 3) == 3) {
-          MI_SCHED_FENCE();  // at most 8 table words in flight: the spectrum already holds 128 registers
-        }
-      }
-    } else {
-      auto SA = [&](int s) -> const cf & { return s < 16 ? X1a[s] : (s < 32 ? X2a[s - 16] : X1a[16]); };
-      auto SB = [&](int s) -> const cf & { return s < 16 ? X1b[s] : (s < 32 ? X2b[s - 16] : X1b[16]); };
-      {
-        cf z0, zK, unused;
-        pair_phase(SA(0), SB(0), mk(1.0f, 0.0f), g0[0], z0, unused);
-        pair_phase(SA(1), SB(1), mk(0.0f, -1.0f), g0[1], zK, unused);
-        A[0] = H == 0 ? cadd(z0, zK) : csub(z0, zK);
-      }
-      MI_UNROLL
-      for (int t = 1; t <= 7; ++t) {
-        const int s = 2 + 2 * (t - 1);
-        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), w64(t), g0[s], g0[s + 1], A[t], A[16 - t]);
-      }
-      {
-        cf zk, zkm;
-        pair_phase(SA(16), SB(16), w64(8), g0[16], zk, zkm);  // Z'[K/2], Z'[3K/2]
-        A[8] = H == 0 ? cadd(zk, zkm) : cmulj(csub(zk, zkm));   // conj(w) = +j
-      }
-      MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        const int s = 17 + 2 * t;
-        cf ok, om;
-        quad_phase<H>(SA(s), SB(s), SA(s + 1), SB(s + 1), cmul(Wb, w64(t)), g0[s], g0[s + 1], ok, om);
-        lds[bB.at(t)] = ok;
+      if (tid != 0) {
+        lds[bA.at(t)] = ok;
         lds[bB.at(15 - t)] = om;
       }
+      if ((t & 3) == 3) {
+        MI_SCHED_FENCE();  // at most 8 table words in flight: the spectrum already holds 128 registers
+      }
+    }
+    if (tid < kSelfLanes) {
+      cf ok, om;
+      quad_phase<H>(Xs[0], Xs[1], Xs[2], Xs[3], Ws, g0[tid], g0[kSelfLanes + tid], ok, om);
+      lds[sl.posK] = ok;
+      lds[sl.posM] = om;  // lanes 0 and 8: the same word, the same value
     }
   }
 
@@ -1174,14 +1151,23 @@ struct FusedKernel {
     (void)sb;
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
-    cf X1a[17], X1b[17], X2a[16], X2b[16];
+    cf X1a[16], X1b[16], X2a[16], X2b[16], Xs[4];
     const cf Wa = ft.WmT[tid];
-    const cf Wb = ft.Wb;
+    const SelfLane sl = self_lane(tid, ft.blockB[0]);
+    const cf Ws = tid < kSelfLanes ? ft.selfW[tid] : mk(1.0f, 0.0f);
+    cf *xch = lds + K;  // kXchWords extra LDS words behind the transform buffer
     {
       cf EA[16], EB[16], OA[16], OB[16];
       b.noff = 0;
       MI_STAMP(sb + 0);
       forward_half(io, b, ft, lds, tid, EA, EB);
+      if (tid == 0) {
+        MI_UNROLL
+        for (int u = 0; u < 16; ++u) {
+          xch[u] = EA[out_pos<16>(u)];
+          xch[16 + u] = EB[out_pos<16>(u)];
+        }
+      }
       MI_STAMP(sb + 1);
       MI_SYNC();  // every thread's last-pass reads done before the next transform's first pass writes
       MI_STAMP(sb + 2);
@@ -1189,51 +1175,54 @@ struct FusedKernel {
       int t2 = tid;
       MI_OPAQUE_VGPR(t2);
       forward_half(io, b, ft, lds, t2, OA, OB);
-      MI_STAMP(sb + 7);
       if (tid == 0) {
-        split_spectrum2<true>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
-      } else {
-        split_spectrum2<false>(EA, EB, OA, OB, Wa, Wb, X1a, X1b, X2a, X2b);
+        MI_UNROLL
+        for (int u = 0; u < 16; ++u) {
+          xch[32 + u] = OA[out_pos<16>(u)];
+          xch[48 + u] = OB[out_pos<16>(u)];
+        }
       }
+      MI_STAMP(sb + 7);
+      split_spectrum2(EA, EB, OA, OB, Wa, X1a, X1b, X2a, X2b);
+    }
+    MI_SYNC();  // thread 0's transform outputs are in xch
+    Xs[0] = Xs[1] = Xs[2] = Xs[3] = mk(0.0f, 0.0f);
+    if (tid < kSelfLanes) {
+      quad_split(xch[sl.srcK], xch[sl.srcM], xch[32 + sl.srcK], xch[32 + sl.srcM], Ws, Xs[0], Xs[1], Xs[2], Xs[3]);
     }
     MI_STAMP(sb + 8);
     const int rot = (MI_BID_X >> 3) + cc;
     for (int it = 0; it < 2 * g.P; ++it) {
       const int p = ((it >> 1) + rot) % g.P, h = it & 1;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 32 * T;
-      const f4 *g0 = ft.G0 + p * 33;
+      const f4 *g0 = ft.G0 + p * (2 * kSelfLanes);
       float *half = scr_c + static_cast<long long>(p) * g.Bc + h * (g.Bc >> 1);
-      cf A[16];
       int tl = tid;
       MI_OPAQUE_VGPR(tl);
       int ba = blkA, bb = blkB;
       MI_OPAQUE_VGPR(ba);
       MI_OPAQUE_VGPR(bb);
-      const Bfly<16, 1> bfB(bb);
-      if (tid == 0) {
-        if (h == 0) {
-          phase_inputs2<true, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
-        } else {
-          phase_inputs2<true, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
-        }
+      const Bfly<16, 1> bfA(ba), bfB(bb);
+      if (h == 0) {
+        phase_inputs2<0>(tl, X1a, X1b, X2a, X2b, Xs, Wa, Ws, sl, gt, g0, lds, bfA, bfB);
       } else {
-        if (h == 0) {
-          phase_inputs2<false, 0>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
-        } else {
-          phase_inputs2<false, 1>(tl, X1a, X1b, X2a, X2b, Wa, Wb, gt, g0, A, lds, bfB);
-        }
+        phase_inputs2<1>(tl, X1a, X1b, X2a, X2b, Xs, Wa, Ws, sl, gt, g0, lds, bfA, bfB);
       }
       const int sp = sb + 9 + 10 * (it & 3);
       (void)sp;
       MI_STAMP(sp + 0);
-      // first inverse pass (stride 1), one block at a time; the second block's inputs were
-      // left in its own LDS words by phase_inputs2
-      dft16<+1>(A);
-      lds_put_dft<16, 1>(lds, Bfly<16, 1>(ba), A);
-      MI_SCHED_FENCE();
-      lds_get<16, 1>(lds, bfB, A);
-      dft16<+1>(A);
-      lds_put_dft<16, 1>(lds, bfB, A);
+      MI_SYNC();  // the self lanes' results are in thread 0's blocks
+      // first inverse pass (stride 1), one block at a time, in place
+      {
+        cf V[16];
+        lds_get<16, 1>(lds, bfA, V);
+        dft16<+1>(V);
+        lds_put_dft<16, 1>(lds, bfA, V);
+        MI_SCHED_FENCE();
+        lds_get<16, 1>(lds, bfB, V);
+        dft16<+1>(V);
+        lds_put_dft<16, 1>(lds, bfB, V);
+      }
       MI_STAMP(sp + 1);
       MI_SYNC();
       MI_STAMP(sp + 2);

@@ -40,7 +40,7 @@ class DeviceFilter {
   const cf *tw() const { return dtw_; }
   bool hasFused() const { return hasFused_; }
   bool fusedSplit() const { return fusedSplit_; }  // tables are laid out for fused_split_kernel
-  FusedTables fused() const { return FusedTables{dtw_, dWmT_, dBlockB_, dGT_, dG0_, wb_}; }
+  FusedTables fused() const { return FusedTables{dtw_, dWmT_, dBlockB_, dGT_, dG0_, wb_, dSelfW_}; }
 
  private:
   DeviceFilter() = default;
@@ -55,7 +55,7 @@ class DeviceFilter {
   cf *dGs_ = nullptr, *dGc_ = nullptr, *dWm_ = nullptr, *dtw_ = nullptr;
   // fused-kernel layout of the same spectra (FusedTables)
   bool hasFused_ = false, fusedSplit_ = false;
-  cf *dWmT_ = nullptr;
+  cf *dWmT_ = nullptr, *dSelfW_ = nullptr;
   int *dBlockB_ = nullptr;
   f4 *dGT_ = nullptr, *dG0_ = nullptr;
   cf wb_{1.0f, 0.0f};

@@ -162,12 +162,13 @@ bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const DeviceFilter &f
   static bool attr_set[64] = {};
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));
-  if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
+  if (Cfg::LDS_BYTES_SPLIT > 64 * 1024 && dev < 64 && !attr_set[dev]) {
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_split_kernel<LOG2K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES_SPLIT));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
+  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io,
+                     f.fused());
   return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
 }
 
@@ -241,6 +242,8 @@ void DeviceFilter::Free() {
   (void)hipFree(dBlockB_);
   (void)hipFree(dGT_);
   (void)hipFree(dG0_);
+  (void)hipFree(dSelfW_);
+  dSelfW_ = nullptr;
   dGs_ = dGc_ = dWm_ = dtw_ = dWmT_ = nullptr;
   dBlockB_ = nullptr;
   dGT_ = dG0_ = nullptr;
@@ -286,7 +289,7 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
   }
   if (t.hasFused) {
     if (!(Upload(t.WmT, &dWmT_, error) && Upload(t.blockB, &dBlockB_, error) && Upload(t.GT, &dGT_, error) &&
-          Upload(t.G0, &dG0_, error))) {
+          Upload(t.G0, &dG0_, error) && Upload(t.selfW, &dSelfW_, error))) {
       return false;
     }
     wb_ = t.Wb;

@@ -76,7 +76,8 @@ void BuildFusedLayout(FilterTables *t) {
 // pair (k, Kh-k) carries the two full-length pairs (k, K-k) and (Kh-k, Kh+k).
 bool BuildFusedSplitLayout(FilterTables *t) {
   const Geometry &g = t->geo;
-  if (g.S != 1 || g.log2k < 6 || g.log2k > 15 || g.Oc % 4 != 0 || g.Bc % 4 != 0) {
+  // (half length >= 1024: the kernel spreads thread 0's sets over 17 lanes, so it needs 17 threads)
+  if (g.S != 1 || g.log2k < 11 || g.log2k > 15 || g.Oc % 4 != 0 || g.Bc % 4 != 0) {
     return false;
   }
   const int lh = g.log2k - 1;
@@ -88,7 +89,8 @@ bool BuildFusedSplitLayout(FilterTables *t) {
   t->WmT.assign(T, cf{1.0f, 0.0f});
   t->blockB.assign(T, 0);
   t->GT.assign(static_cast<std::size_t>(P) * 32 * T, f4{0.0f, 0.0f, 0.0f, 0.0f});
-  t->G0.assign(static_cast<std::size_t>(P) * 33, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->G0.assign(static_cast<std::size_t>(P) * 34, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->selfW.assign(17, cf{1.0f, 0.0f});
   t->Wb = t->Wm[J / 2];
   auto pair = [&](int p, int k) {
     const cf gs = t->Gs[static_cast<std::size_t>(p) * K + k];
@@ -108,19 +110,14 @@ bool BuildFusedSplitLayout(FilterTables *t) {
       }
     }
   }
-  for (int p = 0; p < P; ++p) {
-    f4 *g0 = &t->G0[static_cast<std::size_t>(p) * 33];
-    g0[0] = pair(p, 0);
-    g0[1] = pair(p, Kh);
-    for (int s = 1; s <= 7; ++s) {
-      g0[2 + 2 * (s - 1)] = pair(p, s * J);
-      g0[2 + 2 * (s - 1) + 1] = pair(p, Kh - s * J);
-    }
-    g0[16] = pair(p, 8 * J);
-    for (int s = 0; s < 8; ++s) {
-      const int k = J / 2 + s * J;
-      g0[17 + 2 * s] = pair(p, k);
-      g0[17 + 2 * s + 1] = pair(p, Kh - k);
+  // self lanes (thread 0's sets S_0 and S_{J/2}): lane l <= 8: k = l*J, lane l >= 9: k = J/2 + (l-9)*J;
+  // pair 1 = (k, K-k), pair 2 = (Kh-k, Kh+k)  (k = 0: bins 0 and Kh; k = Kh/2: the same pair twice)
+  for (int l = 0; l < 17; ++l) {
+    const int k = l <= 8 ? l * J : J / 2 + (l - 9) * J;
+    t->selfW[l] = t->Wm[k];
+    for (int p = 0; p < P; ++p) {
+      t->G0[(static_cast<std::size_t>(p) * 2 + 0) * 17 + l] = pair(p, k);
+      t->G0[(static_cast<std::size_t>(p) * 2 + 1) * 17 + l] = pair(p, Kh - k);
     }
   }
   t->hasFused = true;

@@ -30,7 +30,7 @@ struct FilterTables {
   // device/common.h); empty when the geometry is outside the fused kernel.
   bool hasFused = false;
   // fusedSplit: the layout is for fused_split_kernel<log2k - 1> (two half-length transforms
-  // per block transform): T = K/64 threads, GT [P][2][16][T], G0 [P][33]. Chosen when
+  // per block transform): T = K/64 threads, GT [P][2][16][T], G0 [P][2][17], selfW [17]. Chosen when
   // K = 32768 (one size past the LDS) and the history length is a multiple of 4.
   bool fusedSplit = false;
   std::vector<cf> WmT;      // [T]
@@ -38,6 +38,7 @@ struct FilterTables {
   std::vector<f4> GT;       // [P][16][T]
   std::vector<f4> G0;       // [P][17]
   cf Wb{1.0f, 0.0f};
+  std::vector<cf> selfW;    // split layout only
 };
 
 // BuildTables flag for the emulation driver only (tests/emu): build the split layout for
