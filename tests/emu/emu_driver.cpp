@@ -123,7 +123,11 @@ template <int LOG2K>
 void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
   const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr};
-  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K>(g, io, ft); });
+  if (io.ext_epilogue) {
+    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true>(g, io, ft); });
+  } else {
+    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false>(g, io, ft); });
+  }
 }
 
 template <int LOG2K>

@@ -388,7 +388,7 @@ struct FusedKernel {
   // overlap-discard (:566-569): compact samples n < Oc are dropped; the kept
   // ones go, still fp32 and phase-planar, to this workgroup's staging plane
   // (plane[i] = y_p[Oc + i]) with lane-contiguous 8-byte stores.
-  template <int R, bool kEvenOc>
+  template <int R, bool kEvenOc, bool kNT = false>
   static MI_DEVICE void plane_write(float *plane, int Oc, int q, const cf *v) {
     MI_UNROLL
     for (int u = 0; u < R; ++u) {
@@ -396,12 +396,17 @@ struct FusedKernel {
       const cf y = v[out_pos<R>(u)];
       if constexpr (kEvenOc) {
         if (n >= Oc) {
-#if defined(MIUPS_EXP_NT_SCRATCH) && !defined(MIUPS_HOST_EMU)  // experiment switch (profiles/)
-          __builtin_nontemporal_store(y.x, plane + (n - Oc));
-          __builtin_nontemporal_store(y.y, plane + (n - Oc) + 1);
-#else
-          *reinterpret_cast<cf *>(plane + (n - Oc)) = y;
+#if !defined(MIUPS_HOST_EMU)
+          if constexpr (kNT) {
+            // planes that another kernel turns into frames: streaming stores, so that they do
+            // not push the phase spectra out of L2 (config 4 +5 %, config 5 +3 %)
+            // (two 4-byte streaming stores measured 2 % faster than one 8-byte one on configs 3 and 5)
+            __builtin_nontemporal_store(y.x, plane + (n - Oc));
+            __builtin_nontemporal_store(y.y, plane + (n - Oc) + 1);
+            continue;
+          }
 #endif
+          *reinterpret_cast<cf *>(plane + (n - Oc)) = y;
         }
       } else {
         if (n >= Oc) {
@@ -525,7 +530,7 @@ struct FusedKernel {
     lds_put_dft<16, S>(lds, bB, B);
   }
   // last pass: stride K/R, natural-order results -> staging plane
-  template <bool kEvenOc>
+  template <bool kEvenOc, bool kNT = false>
   static MI_DEVICE void inv_last(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
@@ -536,7 +541,7 @@ struct FusedKernel {
         lds_get<R0, S0>(lds, Bfly<R0, S0>(q), v);
         apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
         dftR<+1, R0>(v);
-        plane_write<R0, kEvenOc>(plane, Oc, q, v);
+        plane_write<R0, kEvenOc, kNT>(plane, Oc, q, v);
         if ((i & 3) == 3) {
           MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
         }
@@ -547,11 +552,11 @@ struct FusedKernel {
       lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
       apply_twiddles<+1, 16>(A, w0);
       dft16<+1>(A);
-      plane_write<16, kEvenOc>(plane, Oc, tid, A);
+      plane_write<16, kEvenOc, kNT>(plane, Oc, tid, A);
       MI_SCHED_FENCE();
       apply_twiddles<+1, 16>(B, cmul(w0, w32(1)));
       dft16<+1>(B);
-      plane_write<16, kEvenOc>(plane, Oc, tid + T, B);
+      plane_write<16, kEvenOc, kNT>(plane, Oc, tid + T, B);
     }
   }
 
@@ -996,6 +1001,9 @@ struct FusedKernel {
 
   // One channel-block: forward FFT, split, then per phase multiply + inverse FFT
   // into this channel's staging planes (scr_c = [P][Bc] floats).
+  // EXT: the frames are written by interleave_*_kernel (groups narrower than a frame); the
+  // staging planes are then not read back by this kernel and are stored with streaming stores.
+  template <bool EXT>
   static MI_DEVICE void channel_block(const Geometry &g, const IoDesc &io, const BlockIo &b, float *scr_c,
                                       const FusedTables &ft, cf *lds, int tid, int cc) {
     const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
@@ -1088,7 +1096,7 @@ struct FusedKernel {
       }
       MI_OPAQUE_VGPR(tl);
       if (evenOc) {
-        inv_last<true>(plane, b.Oc, lds, ft.tw, tl);
+        inv_last<true, EXT>(plane, b.Oc, lds, ft.tw, tl);
       } else {
         inv_last<false>(plane, b.Oc, lds, ft.tw, tl);
       }
@@ -1241,7 +1249,7 @@ struct FusedKernel {
         MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
-      inv_last<true>(half, g.Oc >> 1, lds, ft.tw, tl);
+      inv_last<true, true>(half, g.Oc >> 1, lds, ft.tw, tl);
       MI_STAMP(sp + 7);
       MI_SYNC();
       MI_STAMP(sp + 8);
@@ -1249,7 +1257,7 @@ struct FusedKernel {
   }
 
   // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
-  template <bool SPLIT = false>
+  template <bool SPLIT, bool EXT>
   static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
@@ -1281,25 +1289,27 @@ struct FusedKernel {
       if constexpr (SPLIT) {
         channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
       } else {
-        channel_block(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+        channel_block<EXT>(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
       }
     }
     MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
-    if (!SPLIT && !io.ext_epilogue) {  // the split form always leaves the frames to interleave_*_kernel
+    if constexpr (!SPLIT && !EXT) {  // the split form always leaves the frames to interleave_*_kernel
       epilogue(g, io, s, c0, blk, scr, lds, tid);
     }
     MI_STAMP(129);
   }
 };
 
-template <int LOG2K>
+// EXT = false: whole-frame groups, frames written by the kernel's own epilogue;
+// EXT = true: io.ext_epilogue, the kernel stops at the staging planes (see channel_block).
+template <int LOG2K, bool EXT>
 MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_kernel(Geometry g,
                                                                                                       IoDesc io,
                                                                                                       FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K>::run(g, io, ft, lds);
+  FusedKernel<LOG2K>::template run<false, EXT>(g, io, ft, lds);
 }
 
 // Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see
@@ -1309,7 +1319,7 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 
                                                                                                             IoDesc io,
                                                                                                             FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K>::template run<true>(g, io, ft, lds);
+  FusedKernel<LOG2K>::template run<true, true>(g, io, ft, lds);
 }
 
 }  // namespace miups

@@ -139,20 +139,27 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
   return src;
 }
 
-template <int LOG2K>
-bool LaunchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
-                 std::string *error) {
+template <int LOG2K, bool EXT>
+bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+                        std::string *error) {
   using Cfg = FusedCfg<LOG2K>;
   static bool attr_set[64] = {};
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));
   if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2K>),
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2K, EXT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
+  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
+}
+
+template <int LOG2K>
+bool LaunchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+                 std::string *error) {
+  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true>(g, io, f, items, st, error)
+                         : LaunchFusedVariant<LOG2K, false>(g, io, f, items, st, error);
 }
 
 template <int LOG2K>
