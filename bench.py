@@ -10,7 +10,7 @@ already resident in HBM: `mi_engine_process_device` on interleaved s32 frames
 overlap-discard -> PCM store, plus the small history-carry kernel).
 
 Workload at N = 1 is BASELINE.json configs[1]: 44.1k -> 176.4k (4x), stereo,
-80 001-tap minimum-phase filter, 256 blocks per channel. The path shards by
+80 001-tap minimum-phase filter, 2048 blocks per channel per launch. The path shards by
 independent streams: with N ranks every rank runs its own stereo
 stream(s) of the same size on its own GPU -- no data-path collective -- so the
 scaling is *weak*; torch.distributed (gloo) is used only for the rendezvous, the
@@ -47,7 +47,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
     # id: (filter file, streams per GPU, channels, blocks per channel, description)
-    2: ("filter_44k_4x_80000_min_phase.json", 1, 2, 256, "44.1k->176.4k 4x stereo, 80k-tap min-phase"),
+    # 2048 blocks = 9.9 min of 44.1 kHz stereo per launch: 8 rounds of workgroups on 256 CUs (a one-round
+    # launch of 256 blocks is 10-15 % slower: lockstep memory phases, launch gap; profiles/r01_summary.md)
+    2: ("filter_44k_4x_80000_min_phase.json", 1, 2, 2048, "44.1k->176.4k 4x stereo, 80k-tap min-phase"),
     3: ("filter_48k_16x_80000_min_phase.json", 1, 8, 256, "48k->768k 16x 8ch, 80k-tap min-phase + EQ"),
     4: ("filter_44k_2x_80000_min_phase.json", 32, 2, 32, "32 stereo streams/GPU, 44.1k 2x 80k-tap"),
     5: ("filter_48k_8x_160000_linear_phase.json", 1, 32, 64, "48k 8x linear 160k-tap, 32ch + EQ"),

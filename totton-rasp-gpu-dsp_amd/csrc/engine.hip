@@ -483,7 +483,10 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   const int byWaves = std::max(1, 8 / std::max(threads / 64, 1));
   const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
   wgCapacity_ = std::max<std::size_t>(capacity, 1);
-  const bool whole = channels_ == 1 || (channels_ == 2 && blocks * streams_ >= capacity);
+  bool whole = channels_ == 1 || (channels_ == 2 && blocks * streams_ >= capacity);
+  if (channels_ == 2 && std::getenv("MIUPS_EXP_STEREO_EXT")) {  // experiment switch (profiles/)
+    whole = false;
+  }
   cg_ = whole ? channels_ : 1;
   groups_ = channels_ / cg_;
 }
