@@ -208,6 +208,36 @@ def test_wide_frame_channels_are_independent_and_ordered(ups, gpu):
     assert np.abs(y[-1000:].mean(axis=0) - want).max() <= 1e-5
 
 
+@pytest.mark.parametrize("fmt", ["s32", "f32"])
+def test_bench_sized_stereo_batch_whole_frame_epilogue(ups, O, gpu, fmt):
+    """The bench's own shape: a stereo call big enough to give every CU a workgroup (256 blocks
+    at K = 16384) takes the whole-frame path -- two channels per workgroup, frames written by
+    the kernel's own epilogue. The same stream fed in 64-block calls takes the other path (one
+    channel per workgroup + interleave kernel). Same arithmetic per channel: the outputs must
+    be bit-identical, and channel 1 must match fp64 truth."""
+    path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+    h, taps, fft, block, L = O.read_filter(path)
+    filt = ups.Filter(path, device=gpu)
+    pcm = ups.PCM_NAMES[fmt]
+    eng = ups.Engine(filt, 1, 2, pcm, pcm)
+    nin, blocks = eng.in_frames, 256
+    xf = np.clip(np.random.default_rng(11).standard_normal((blocks * nin, 2)) * 0.1, -1, 1).astype(np.float32)
+    raw = xf if fmt == "f32" else O.float_to_pcm(xf.reshape(-1), fmt)
+    whole = eng.process_host(raw, blocks).copy()
+    eng.reset()
+    step = 64
+    per_call = step * nin * 2 * 4  # bytes: both formats are 4-byte samples
+    raw_b = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    parts = [eng.process_host(raw_b[i * per_call:(i + 1) * per_call].view(np.float32 if fmt == "f32" else np.uint8), step).copy()
+             for i in range(blocks // step)]
+    np.testing.assert_array_equal(whole.view(np.uint8).reshape(-1), np.concatenate([p.view(np.uint8).reshape(-1) for p in parts]))
+    xin = xf if fmt == "f32" else O.pcm_to_float(raw, fmt).reshape(-1, 2)
+    y = (whole.view(np.float32) if fmt == "f32" else O.pcm_to_float(whole, fmt)).reshape(blocks * block, 2)
+    truth = O.truth_stream(xin[:, 1], h, L, blocks, block).reshape(-1)
+    lsb = 0.0 if fmt == "f32" else 2.0**-31
+    assert np.abs(y[:, 1] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
+
+
 def test_history_carries_across_calls_and_reset(ups, O, gpu):
     path = ROOT / "data" / "coefficients" / "filter_48k_16x_80000_min_phase.json"
     filt = ups.Filter(path, device=gpu)
