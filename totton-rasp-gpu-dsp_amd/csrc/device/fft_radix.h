@@ -179,6 +179,40 @@ MI_DEVICE void apply_twiddles_out(cf *v, cf w) {
   }
 }
 
+// The fifteen powers w^1..w^15 of a radix-16 butterfly's twiddle (same product tree as
+// apply_twiddles), for two butterflies that share them: t[u-1] = w^u. DIR > 0 conjugates.
+template <int DIR>
+MI_DEVICE void make_twiddles16(cf w, cf *t) {
+  if (DIR > 0) {
+    w = cconj(w);
+  }
+  t[0] = w;
+  t[1] = cmul(w, w);
+  t[2] = cmul(t[1], w);
+  t[3] = cmul(t[1], t[1]);
+  t[4] = cmul(t[3], w);
+  t[5] = cmul(t[3], t[1]);
+  t[6] = cmul(t[3], t[2]);
+  t[7] = cmul(t[3], t[3]);
+  MI_UNROLL
+  for (int u = 1; u <= 7; ++u) {
+    t[7 + u] = cmul(t[7], t[u - 1]);
+  }
+}
+// v[u] *= t[u-1] (inputs of a DIT butterfly) / v[out_pos(u)] *= t[u-1] (outputs of a DIF one)
+MI_DEVICE void mul_twiddles16(cf *v, const cf *t) {
+  MI_UNROLL
+  for (int u = 1; u < 16; ++u) {
+    v[u] = cmul(v[u], t[u - 1]);
+  }
+}
+MI_DEVICE void mul_twiddles16_out(cf *v, const cf *t) {
+  MI_UNROLL
+  for (int u = 1; u < 16; ++u) {
+    v[out_pos<16>(u)] = cmul(v[out_pos<16>(u)], t[u - 1]);
+  }
+}
+
 // Twiddle table layout: for q = 1..log2k, entries exp(-2*pi*i*k / 2^q) for
 // k in [0, 2^(q-1)) start at offset 2^(q-1) - 1. (Total 2^log2k - 1 entries.)
 MI_HD constexpr int tw_offset(int q) { return (1 << (q - 1)) - 1; }

@@ -483,6 +483,18 @@ struct FusedKernel {
     cf A[16], B[16];
     lds_get<16, S>(lds, bA, A);
     lds_get<16, S>(lds, bB, B);
+    if constexpr (T % S == 0) {  // both butterflies use the same twiddle: one power tree (-9 % VALU in this pass)
+      cf tw16[15];
+      make_twiddles16<-1>(wA, tw16);
+      dft16<-1>(A);
+      mul_twiddles16_out(A, tw16);
+      lds_put_dft<16, S>(lds, bA, A);
+      MI_SCHED_FENCE();
+      dft16<-1>(B);
+      mul_twiddles16_out(B, tw16);
+      lds_put_dft<16, S>(lds, bB, B);
+      return;
+    }
     dft16<-1>(A);
     apply_twiddles_out<-1, 16>(A, wA);
     lds_put_dft<16, S>(lds, bA, A);
@@ -521,6 +533,18 @@ struct FusedKernel {
     cf A[16], B[16];
     lds_get<16, S>(lds, bA, A);
     lds_get<16, S>(lds, bB, B);
+    if constexpr (T % S == 0) {
+      cf tw16[15];
+      make_twiddles16<+1>(wA, tw16);
+      mul_twiddles16(A, tw16);
+      dft16<+1>(A);
+      lds_put_dft<16, S>(lds, bA, A);
+      MI_SCHED_FENCE();
+      mul_twiddles16(B, tw16);
+      dft16<+1>(B);
+      lds_put_dft<16, S>(lds, bB, B);
+      return;
+    }
     apply_twiddles<+1, 16>(A, wA);
     dft16<+1>(A);
     lds_put_dft<16, S>(lds, bA, A);
