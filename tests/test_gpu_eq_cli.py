@@ -39,7 +39,8 @@ def test_empty_eq_profile_is_unity(ups, gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fname,fs", [("filter_48k_16x_80000_min_phase.json", 768000.0),
-                                      ("filter_44k_4x_80000_min_phase.json", 705600.0)])
+                                      ("filter_44k_4x_80000_min_phase.json", 705600.0),
+                                      ("filter_44k_2x_80000_min_phase.json", 705600.0)])  # K = 32768: split kernel tables
 def test_eq_folded_into_filter_spectrum(ups, O, gpu, fname, fs):
     """H_total[k] = H_fir[k] * EQ(k fs/N) on all N bins (this repo's definition of
     the fusion; the reference has no call site, so only the per-bin EQ values are
