@@ -24,6 +24,7 @@ CONFIGS = {2: ("filter_44k_4x_80000_min_phase.json", 2, 256, None),
            4: ("filter_44k_2x_80000_min_phase.json", 2, 1024, None),   # split kernel: fwd_first..fwd_last = both halves
            5: ("filter_48k_8x_160000_linear_phase.json", 32, 64, 768000.0)}
 fname, channels, blocks, eq_fs = CONFIGS[int(os.environ.get("STAMPS_CONFIG", "2"))]
+blocks = int(os.environ.get("STAMPS_BLOCKS", blocks))
 filt = ups.Filter(ROOT / "data" / "coefficients" / fname)
 if eq_fs:
     filt.set_eq(json.loads((ROOT / "tests" / "golden" / "g4_eq_profiles.json").read_text())["opra10"], eq_fs)

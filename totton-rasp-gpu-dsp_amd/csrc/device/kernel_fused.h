@@ -62,11 +62,14 @@
 // buffer of their own; no product build contains them.
 #if defined(MIUPS_STAMPS) && !defined(MIUPS_HOST_EMU)
 __device__ unsigned long long mi_stamps[32][8][192];
-#define MI_STAMP(id)                                                                       \
-  do {                                                                                     \
-    if ((MI_TID_X & 63) == 0 && MI_BID_X < 32) {                                           \
-      mi_stamps[MI_BID_X][MI_TID_X >> 6][(id)] = __builtin_amdgcn_s_memtime();             \
-    }                                                                                      \
+#if !defined(MIUPS_STAMP_BASE)
+#define MIUPS_STAMP_BASE 0  // first of the 32 recorded workgroups (a later round: -DMIUPS_STAMP_BASE=1024)
+#endif
+#define MI_STAMP(id)                                                                                   \
+  do {                                                                                                 \
+    if ((MI_TID_X & 63) == 0 && MI_BID_X >= MIUPS_STAMP_BASE && MI_BID_X < MIUPS_STAMP_BASE + 32) {   \
+      mi_stamps[MI_BID_X - MIUPS_STAMP_BASE][MI_TID_X >> 6][(id)] = __builtin_amdgcn_s_memtime();     \
+    }                                                                                                  \
   } while (0)
 #else
 #define MI_STAMP(id)
@@ -1120,7 +1123,11 @@ struct FusedKernel {
       }
       MI_OPAQUE_VGPR(tl);
       if (evenOc) {
+#if defined(MIUPS_EXP_NT_PLANES_ALWAYS)  // experiment switch (profiles/): streaming plane stores with the in-kernel epilogue too
+        inv_last<true, true>(plane, b.Oc, lds, ft.tw, tl);
+#else
         inv_last<true, EXT>(plane, b.Oc, lds, ft.tw, tl);
+#endif
       } else {
         inv_last<false>(plane, b.Oc, lds, ft.tw, tl);
       }
