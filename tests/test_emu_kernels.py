@@ -48,8 +48,8 @@ CASES = [
     (1024, 257, 4, "fused", 2, 3, 3, 2),  # odd channel count, chunked launch
     (1024, 257, 16, "fused", 1, 2, 4, 1),
     (1024, 257, 4, "staged", 2, 2, 2, 2),
-    (4096, 1025, 2, "fused", 1, 8, 1, 2),  # 8-channel group
-    (4096, 1025, 8, "fused", 1, 12, 2, 1),  # 12 channels -> groups of 6
+    (4096, 1025, 2, "fused", 1, 8, 1, 2),  # 8 channels: planar input, one channel per workgroup, interleave kernel
+    (4096, 1025, 8, "fused", 1, 12, 2, 1),  # 12 channels
     (8192, 2049, 1, "fused", 1, 1, 1, 2),  # K = 4096 (radices 16,16,16)
 ]
 
