@@ -1125,6 +1125,8 @@ struct FusedKernel {
       if (evenOc) {
 #if defined(MIUPS_EXP_NT_PLANES_ALWAYS)  // experiment switch (profiles/): streaming plane stores with the in-kernel epilogue too
         inv_last<true, true>(plane, b.Oc, lds, ft.tw, tl);
+#elif defined(MIUPS_EXP_NO_NT_PLANES)  // experiment switch (profiles/): cached plane stores for the interleave kernels too
+        inv_last<true, false>(plane, b.Oc, lds, ft.tw, tl);
 #else
         inv_last<true, EXT>(plane, b.Oc, lds, ft.tw, tl);
 #endif
