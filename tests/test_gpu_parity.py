@@ -10,6 +10,7 @@ Tolerances (fp32 path, stated per SURVEY §8c):
 from __future__ import annotations
 
 import json
+import sys
 
 import numpy as np
 import pytest
@@ -236,6 +237,41 @@ def test_bench_sized_stereo_batch_whole_frame_epilogue(ups, O, gpu, fmt):
     truth = O.truth_stream(xin[:, 1], h, L, blocks, block).reshape(-1)
     lsb = 0.0 if fmt == "f32" else 2.0**-31
     assert np.abs(y[:, 1] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
+
+
+@pytest.mark.parametrize("channels,blocks,in_off,out_off", [
+    (2, 256, 4, 0),    # whole-frame path, input 4-byte aligned only: per-sample loads instead of 16-byte frame pairs
+    (2, 256, 0, 4),    # whole-frame path, output 4-byte aligned only: scalar epilogue
+    (2, 3, 4, 4),      # one channel per workgroup + scalar interleave kernel
+    (8, 2, 8, 12),     # planar input + scalar interleave kernel
+    (1, 2, 4, 8),      # mono: 8-byte complex-word loads need 8-byte alignment
+])
+def test_device_buffers_with_minimal_alignment(ups, O, gpu, channels, blocks, in_off, out_off):
+    """A caller's device buffers need only be sample-aligned: every vector fast path has to fall
+    back on its own. Same stream through aligned and deliberately offset device addresses:
+    bit-identical output."""
+    sys.path.insert(0, str(ROOT))
+    from bench import Hip
+
+    hip = Hip()
+    hip.check(hip.lib.hipSetDevice(gpu), "hipSetDevice")
+    path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+    filt = ups.Filter(path, device=gpu)
+    eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+    x = (np.clip(np.random.default_rng(3).standard_normal((blocks * eng.in_frames, channels)) * 0.1, -1, 1)
+         * (2**31 - 1)).astype("<i4")
+    want = eng.process_host(x, blocks).copy()
+    eng.reset()
+    nin, nout = eng.in_bytes(blocks), eng.out_bytes(blocks)
+    d_in, d_out = hip.malloc(nin + 64), hip.malloc(nout + 64)
+    hip.h2d(d_in + in_off, x)
+    eng.process_device(d_in + in_off, d_out + out_off, blocks)
+    hip.sync()
+    got = np.empty(nout, np.uint8)
+    hip.d2h(got, d_out + out_off)
+    hip.check(hip.lib.hipFree(d_in), "hipFree")
+    hip.check(hip.lib.hipFree(d_out), "hipFree")
+    np.testing.assert_array_equal(got, want)
 
 
 def test_history_carries_across_calls_and_reset(ups, O, gpu):
