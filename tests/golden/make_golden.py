@@ -181,8 +181,10 @@ def g4():
         pre, bands = O.ref_eq_parse(text)
         res[f"{name}_preamp"] = np.float64(pre)
         res[f"{name}_bands"] = bands
+        # "lin160k": the N = 262144 grid of BASELINE configs[4] (160 001-tap linear filter, 768 kHz out)
         for tag, (bins, fft, fs) in {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0),
-                                     "small": (513, 1024, 44100.0 * 16)}.items():
+                                     "small": (513, 1024, 44100.0 * 16),
+                                     "lin160k": (131073, 262144, 768000.0)}.items():
             full = O.ref_eq_response(text, bins, fft, fs)
             idx = np.unique(np.round(np.logspace(0, np.log10(bins - 1), 64)).astype(int))
             idx = np.unique(np.concatenate([[0], idx, [bins - 1]]))
@@ -232,13 +234,15 @@ def g6(tmp: Path):
 
 def main():
     assert O.have_ref(), "run `make -C oracle` where /root/reference exists"
+    only = set(sys.argv[1:])  # e.g. `make_golden.py g4` regenerates one family
     with tempfile.TemporaryDirectory() as t:
         tmp = Path(t)
-        g1(tmp)
-        g2(tmp)
-        g6(tmp)
-    g3()
-    g4()
+        for name, fn in (("g1", g1), ("g2", g2), ("g6", g6)):
+            if not only or name in only:
+                fn(tmp)
+    for name, fn in (("g3", g3), ("g4", g4)):
+        if not only or name in only:
+            fn()
     print("golden written to", OUT)
 
 

@@ -13,7 +13,8 @@ from conftest import GOLDEN, ROOT, real_input, rel_err
 
 BIN = ROOT / "totton-rasp-gpu-dsp_amd" / "bin" / "alsa_streamer"
 PROFILES = json.loads((GOLDEN / "g4_eq_profiles.json").read_text())
-GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16)}
+GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16),
+         "lin160k": (131073, 262144, 768000.0)}  # the N = 262144 grid of BASELINE configs[4]
 
 
 # ------------------------------------------------------------------ EQ (GPU) --
@@ -65,6 +66,35 @@ def test_eq_folded_into_filter_spectrum(ups, O, gpu, fname, fs):
     v.reset()
     np.testing.assert_array_equal(np.stack([u.process_block(x[b * nin:(b + 1) * nin]) for b in range(nb)]), plain)
     assert rel_err(np.stack([v.process_block(x[b * nin:(b + 1) * nin]) for b in range(nb)]), want) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname,fs,channels,blocks", [
+    ("filter_48k_16x_80000_min_phase.json", 768000.0, 8, 4),       # BASELINE configs[2] as benched: 8 ch + EQ
+    ("filter_48k_8x_160000_linear_phase.json", 768000.0, 32, 3),   # BASELINE configs[4] as benched: 32 ch + EQ, N = 262144
+])
+def test_bench_configs_with_eq_as_benched(ups, O, gpu, fname, fs, channels, blocks):
+    """bench.py --config 3 / --config 5 exactly as timed: mi_filter_set_eq(opra10) on the shared filter, then the
+    batched engine on interleaved s32 frames of `channels` channels (planarize -> fused -> interleave kernels).
+    Checked per channel against the fp64 statement of the fusion on the filter's own N-point grid (for config 5
+    that is the 131 073-bin grid of N = 262144): 1 LSB + 1e-5 * max|y|."""
+    path = ROOT / "data" / "coefficients" / fname
+    h, taps, fft, block, L = O.read_filter(path)
+    text = PROFILES["opra10"]
+    filt = ups.Filter(path, device=gpu)
+    filt.set_eq(text, fs)
+    eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+    assert eng.path == "fused"
+    nin = eng.in_frames
+    xf = np.clip(np.random.default_rng(31).standard_normal((blocks * nin, channels)) * 0.02, -1, 1).astype(np.float32)
+    raw = O.float_to_pcm(xf.reshape(-1), "s32")
+    xin = O.pcm_to_float(raw, "s32").reshape(blocks * nin, channels)
+    y = O.pcm_to_float(eng.process_host(raw, blocks), "s32").reshape(blocks * block, channels)
+    eq_half = O.eq_response(text, fft // 2 + 1, fft, fs)
+    for c in sorted({0, 1, channels // 2, channels - 1}):
+        want = O.eq_fused_stream_truth(xin[:, c], h, L, fft, block, blocks, eq_half).reshape(-1)
+        assert np.abs(want).max() < 0.9          # nothing clamps: the comparison is of the filter, not of the limiter
+        assert np.abs(y[:, c] - want).max() <= 2.0**-31 + 1e-5 * np.abs(want).max()
 
 
 @pytest.mark.gpu

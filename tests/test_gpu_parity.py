@@ -96,7 +96,7 @@ def test_real_geometry_vs_golden(ups, gpu, name):
     np.testing.assert_allclose(np.sqrt((y.astype(np.float64) ** 2).sum(axis=1)), g[f"{name}_truth_l2"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["44k_4x", "48k_16x"])
+@pytest.mark.parametrize("name", sorted(G3))  # incl. the split kernel (44k_2x, K = 32768) and the 160 001-tap filter
 def test_ref_compat_spectrum_matches_vulkan_path_simulation(ups, gpu, name):
     meta = G3[name]
     g = np.load(GOLDEN / "g3_real.npz")
@@ -189,6 +189,52 @@ def test_wide_frames_match_truth_across_calls(ups, O, gpu, fname, channels, stre
         for c in sorted({0, 1, channels // 2, channels - 1}):
             truth = O.truth_stream(x[s, :, c], h, L, calls * blocks, block).reshape(-1)
             assert np.abs(y[s, :, c] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
+
+
+# ---- float -> PCM on the device: clamp + truncate, bit for bit ---------------------
+def _pcm_case_filter(make_filter, case):
+    rng = np.random.default_rng(42)
+    if case == "real2x":
+        return ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.json"
+    fft, block, L = {"L4": (1024, 768, 4), "L16": (1024, 768, 16), "L16odd": (1024, 720, 16)}[case]
+    n = fft - block + 1
+    taps = (rng.standard_normal(n) * 0.55 / np.sqrt(n / L)).astype(np.float32)  # output sigma ~ 0.55 x the input's
+    return make_filter(taps, fft, block, L, name=f"pcm_{case}")
+
+
+@pytest.mark.parametrize("case,channels,blocks", [
+    ("L4", 2, 2048),      # whole-frame stereo, 8 planes: epilogue_vec (s32) / epilogue_scalar (s16, s24)
+    ("L16", 2, 2048),     # whole-frame stereo, 32 planes, Bc % 4 == 0: epilogue_quad
+    ("L16odd", 2, 2048),  # Bc = 45, odd history: epilogue_tiled, plane_write without the even-Oc fast path
+    ("L16", 8, 8),        # wide frames: interleave_quad_kernel (s32) / interleave_scalar_kernel (s16, s24)
+    ("real2x", 2, 4),     # K = 32768 split kernel: interleave kernels reading split planes
+])
+@pytest.mark.parametrize("fmt", ["s16", "s24", "s32"])
+def test_device_float_to_pcm_saturates_bit_exact(ups, O, gpu, make_filter, case, channels, blocks, fmt):
+    """ConvertFloatToPcm (alsa_common.cpp:87-127): clamp to [-1, 0.9999695 | 0.9999999], scale in fp32,
+    truncate toward zero; NaN -> the upper clamp (std::min/std::max comparison order). The engine is run
+    twice on the same loud input -- once with f32 output, once with PCM output: the float values are the
+    same (same kernels, same order), so the PCM bytes must equal the oracle's conversion of those floats
+    EXACTLY. The input drives a large share of the outputs past +-1 and, in its last block, to +-inf / NaN."""
+    path = _pcm_case_filter(make_filter, case)
+    filt = ups.Filter(path, device=gpu)
+    ef = ups.Engine(filt, 1, channels, ups.PCM_F32, ups.PCM_F32)
+    ep = ups.Engine(filt, 1, channels, ups.PCM_F32, ups.PCM_NAMES[fmt])
+    nin = ef.in_frames
+    rng = np.random.default_rng(99)
+    x = (rng.standard_normal((blocks * nin, channels)) * 1.5).astype(np.float32)
+    x[:nin:7, 0] = 1.0e9            # far beyond full scale
+    x[1:nin:7, channels - 1] = -1.0e9
+    x[(blocks - 1) * nin + 3, 0] = np.inf             # the whole last block of channel 0 becomes NaN / inf
+    x[(blocks - 1) * nin + 5, channels - 1] = -np.inf
+    yf = ef.process_host(x, blocks).view(np.float32)
+    got = ep.process_host(x, blocks)
+    B = filt.config["block_size"]
+    y = yf.reshape(blocks * B, channels)
+    assert np.isnan(y[-B:, 0]).any() and (np.abs(y[:-B]) > 1.0).mean() > 0.05 and (np.abs(y[:-B]) < 1.0).mean() > 0.05
+    np.testing.assert_array_equal(got, O.float_to_pcm(yf, fmt))
+    # and the host-side converter of the C ABI (mi_float_to_pcm) agrees on the same floats
+    np.testing.assert_array_equal(ups.float_to_pcm(yf, ups.PCM_NAMES[fmt]), O.float_to_pcm(yf, fmt))
 
 
 def test_wide_frame_channels_are_independent_and_ordered(ups, gpu):

@@ -172,7 +172,8 @@ def test_pcm_conversion_bit_exact_vs_oracle(ups, O, fmt):
 
 # ---- EQ -----------------------------------------------------------------------
 PROFILES = json.loads((GOLDEN / "g4_eq_profiles.json").read_text())
-GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16)}
+GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16),
+         "lin160k": (131073, 262144, 768000.0)}  # the N = 262144 grid of BASELINE configs[4]
 
 
 @pytest.mark.parametrize("name", sorted(PROFILES))

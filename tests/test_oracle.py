@@ -98,7 +98,8 @@ def test_oracle_matches_compiled_reference_live(O, make_filter):
 
 # ---- EQ ------------------------------------------------------------------------
 PROFILES = json.loads((GOLDEN / "g4_eq_profiles.json").read_text())
-GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16)}
+GRIDS = {"768k": (65537, 131072, 768000.0), "705k": (65537, 131072, 705600.0), "small": (513, 1024, 44100.0 * 16),
+         "lin160k": (131073, 262144, 768000.0)}  # the N = 262144 grid of BASELINE configs[4]
 
 
 @pytest.mark.parametrize("name", sorted(PROFILES))

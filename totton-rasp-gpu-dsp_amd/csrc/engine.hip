@@ -187,6 +187,9 @@ bool DispatchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, u
     if (g.log2k == 15) {
       return LaunchFusedSplit<14>(g, io, f, items, st, error);
     }
+    if (g.log2k == 14) {  // experiment switch MIUPS_EXP_FORCE_SPLIT (profiles/): two 64 KiB workgroups per CU
+      return LaunchFusedSplit<13>(g, io, f, items, st, error);
+    }
     if (error) {
       *error = "split fused kernel does not cover this geometry";
     }
@@ -268,6 +271,9 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
   f->config_ = config;
   f->taps_ = std::move(taps);
   f->flags_ = flags & kLoadRefCompatSpectrum;  // the only load flag of the public boundary
+  if (config.fftSize / (2 * std::max<std::size_t>(config.upsampleFactor, 1)) == 16384 && std::getenv("MIUPS_EXP_FORCE_SPLIT")) {
+    f->flags_ |= kLoadInternalForceSplit;  // experiment switch (profiles/): K = 16384 as two 8192-point halves
+  }
   if (!f->Rebuild(nullptr, error)) {
     return nullptr;
   }
