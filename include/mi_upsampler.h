@@ -137,12 +137,36 @@ const char *mi_engine_path(const mi_engine *e);
 /* Process `blocks` consecutive blocks of every stream. d_in / d_out are DEVICE
  * pointers: stream s starts at base + s*stride bytes and holds interleaved
  * frames [frame][channel]. `hip_stream` is a hipStream_t (NULL = default
- * stream); the call only enqueues work. */
+ * stream); the call only enqueues work (see "Stream contract" below). */
 int mi_engine_process_device(mi_engine *e, const void *d_in, size_t in_stream_stride_bytes, void *d_out,
                              size_t out_stream_stride_bytes, size_t blocks, void *hip_stream);
-/* Same with HOST buffers: copies in, runs, copies out, synchronises. */
+/* Same with HOST buffers: copies in, runs, copies out, synchronises. The call is cut into sub-batches whose H2D
+ * copy, kernels and D2H copy overlap on three streams (double-buffered device staging). Buffers from mi_host_alloc
+ * (pinned) are moved by DMA directly; pageable buffers work, at the runtime's staging speed. */
 int mi_engine_process_host(mi_engine *e, const void *h_in, size_t in_stream_stride_bytes, void *h_out,
                            size_t out_stream_stride_bytes, size_t blocks);
+/* pinned host memory for the buffers of mi_engine_process_host (hipHostMalloc / hipHostFree) */
+void *mi_host_alloc(size_t bytes);
+void mi_host_free(void *p);
+
+/* Stream contract of an engine: every call is ordered after the previous call on the same engine, whatever streams
+ * the two calls used (the engine chains them with events), so history and staging buffers never race. An engine is
+ * not thread-safe: one host thread at a time.
+ *
+ * Filter changes between blocks:
+ *   mi_filter_set_eq on a filter that engines are using is glitch-free: the new tables are built and uploaded beside
+ *   the live ones and published atomically; calls enqueued earlier finish on the old spectrum, the next call uses the
+ *   new one; a failed rebuild leaves the old spectrum in place. mi_filter_generation counts published table sets,
+ *   mi_engine_last_generation tells which one the engine's latest call used.
+ *   mi_engine_rebind switches an engine to ANOTHER resident filter (other ratio / phase / rate family) at a block
+ *   boundary. The carried input history is kept when both filters keep the same number of history frames and
+ *   reset_history is 0; otherwise it is zeroed (the state after LoadFilter, vulkan_streaming_upsampler.cpp:741). */
+int mi_engine_rebind(mi_engine *e, mi_filter *f, int reset_history);
+unsigned long long mi_filter_generation(const mi_filter *f);
+unsigned long long mi_engine_last_generation(const mi_engine *e);
+/* test hook: the next table upload of this filter fails after the host-side build (tests that a failed EQ change
+ * leaves the filter usable) */
+void mi_debug_fail_next_table_upload(mi_filter *f);
 
 /* Timing of the dominant kernel(s) on the stream they run on: with slots > 0
  * every process call brackets its main kernel(s) with a hipEvent pair (ring of

@@ -16,6 +16,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 os.environ.setdefault("MIUPS_LIB", str(ROOT / "totton-rasp-gpu-dsp_amd" / "lib_ablate" / "libmi_upsampler_STAMPS.so"))
 BRIEF = os.environ.get("STAMPS_BRIEF") == "1"
+os.environ.setdefault("MIUPS_EXP_HOST_SUBBATCHES", "1")  # one ProcessDevice call per process_host: the bench's kernel path
 sys.path.insert(0, str(ROOT))
 import totton_rasp_gpu_dsp_amd as ups  # noqa: E402
 

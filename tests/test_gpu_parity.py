@@ -223,15 +223,16 @@ def test_device_float_to_pcm_saturates_bit_exact(ups, O, gpu, make_filter, case,
     nin = ef.in_frames
     rng = np.random.default_rng(99)
     x = (rng.standard_normal((blocks * nin, channels)) * 1.5).astype(np.float32)
-    x[:nin:7, 0] = 1.0e9            # far beyond full scale
-    x[1:nin:7, channels - 1] = -1.0e9
+    if case != "real2x":            # (an 80k-tap tail would ring above full scale for the whole test)
+        x[:nin:7, 0] = 1.0e9        # far beyond full scale
+        x[1:nin:7, channels - 1] = -1.0e9
     x[(blocks - 1) * nin + 3, 0] = np.inf             # the whole last block of channel 0 becomes NaN / inf
     x[(blocks - 1) * nin + 5, channels - 1] = -np.inf
     yf = ef.process_host(x, blocks).view(np.float32)
     got = ep.process_host(x, blocks)
     B = filt.config["block_size"]
     y = yf.reshape(blocks * B, channels)
-    assert np.isnan(y[-B:, 0]).any() and (np.abs(y[:-B]) > 1.0).mean() > 0.05 and (np.abs(y[:-B]) < 1.0).mean() > 0.05
+    assert np.isnan(y[-B:, 0]).any() and (np.abs(y[:-B]) > 1.0).mean() > 0.02 and (np.abs(y[:-B]) < 1.0).mean() > 0.02
     np.testing.assert_array_equal(got, O.float_to_pcm(yf, fmt))
     # and the host-side converter of the C ABI (mi_float_to_pcm) agrees on the same floats
     np.testing.assert_array_equal(ups.float_to_pcm(yf, ups.PCM_NAMES[fmt]), O.float_to_pcm(yf, fmt))

@@ -76,6 +76,12 @@ def _load():
         "mi_engine_path": (cp, [vp]),
         "mi_engine_process_device": (i32, [vp, vp, sz, vp, sz, sz, vp]),
         "mi_engine_process_host": (i32, [vp, vp, sz, vp, sz, sz]),
+        "mi_host_alloc": (vp, [sz]),
+        "mi_host_free": (None, [vp]),
+        "mi_engine_rebind": (i32, [vp, vp, i32]),
+        "mi_filter_generation": (C.c_ulonglong, [vp]),
+        "mi_engine_last_generation": (C.c_ulonglong, [vp]),
+        "mi_debug_fail_next_table_upload": (None, [vp]),
         "mi_engine_enable_kernel_timing": (i32, [vp, i32]),
         "mi_engine_last_kernel_ms": (dbl, [vp]),
         "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
@@ -116,7 +122,8 @@ EXPORTED_SYMBOLS = [
     "mi_ups_set_eq", "mi_filter_load", "mi_filter_from_taps", "mi_filter_get_config", "mi_filter_set_eq",
     "mi_eq_response_device", "mi_filter_release", "mi_engine_create", "mi_engine_destroy", "mi_engine_reset",
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
-    "mi_engine_process_host", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
+    "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_engine_rebind", "mi_filter_generation",
+    "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
     "mi_engine_kernel_ms_stats", "mi_read_filter",
     "mi_resolve_filter_path", "mi_parse_format", "mi_bytes_per_sample", "mi_pcm_to_float", "mi_float_to_pcm",
     "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
@@ -228,8 +235,14 @@ class Filter:
         return _cfg(c)
 
     def set_eq(self, apo_text: str, fs_out: float) -> None:
+        """Glitch-free: engines already running keep the old spectrum for the calls they have enqueued and use the
+        new one from their next call on; on failure the old spectrum stays (include/mi_upsampler.h)."""
         if lib.mi_filter_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
             raise UpsamplerError(last_error())
+
+    @property
+    def generation(self) -> int:
+        return int(lib.mi_filter_generation(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -269,12 +282,16 @@ class Engine:
         if rc != MI_OK:
             raise UpsamplerError(last_error())
 
-    def process_host(self, x: np.ndarray, blocks: int) -> np.ndarray:
-        """x: raw bytes / array laid out [stream][frame][channel]; returns uint8 bytes same layout."""
+    def process_host(self, x: np.ndarray, blocks: int, out: np.ndarray | None = None) -> np.ndarray:
+        """x: raw bytes / array laid out [stream][frame][channel]; returns uint8 bytes same layout (written into `out`
+        when given, e.g. a PinnedBuffer's array)."""
         raw = np.ascontiguousarray(x).view(np.uint8).reshape(-1)
         if raw.size != self.in_bytes(blocks) * self.streams:
             raise UpsamplerError(f"input holds {raw.size} bytes, expected {self.in_bytes(blocks) * self.streams}")
-        out = np.empty(self.out_bytes(blocks) * self.streams, dtype=np.uint8)
+        if out is None:
+            out = np.empty(self.out_bytes(blocks) * self.streams, dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != self.out_bytes(blocks) * self.streams or not out.flags.c_contiguous:
+            raise UpsamplerError("out must be a contiguous uint8 array of out_bytes(blocks) * streams bytes")
         rc = lib.mi_engine_process_host(self._h, raw.ctypes.data_as(C.c_void_p), self.in_bytes(blocks),
                                         out.ctypes.data_as(C.c_void_p), self.out_bytes(blocks), blocks)
         if rc != MI_OK:
@@ -284,6 +301,19 @@ class Engine:
     def reset(self) -> None:
         if lib.mi_engine_reset(self._h) != MI_OK:
             raise UpsamplerError(last_error())
+
+    def rebind(self, filt: "Filter", reset_history: bool = False) -> None:
+        """Switch to another resident filter at a block boundary (mi_engine_rebind)."""
+        if lib.mi_engine_rebind(self._h, filt._h, int(reset_history)) != MI_OK:
+            raise UpsamplerError(last_error())
+        self.filter = filt
+        self.in_frames = int(lib.mi_engine_in_frames_per_block(self._h))
+        self.out_frames = int(lib.mi_engine_out_frames_per_block(self._h))
+        self.path = lib.mi_engine_path(self._h).decode()
+
+    @property
+    def last_generation(self) -> int:
+        return int(lib.mi_engine_last_generation(self._h))
 
     def enable_kernel_timing(self, slots: int = 1) -> None:
         if lib.mi_engine_enable_kernel_timing(self._h, int(slots)) != MI_OK:
@@ -302,6 +332,25 @@ class Engine:
         if getattr(self, "_h", None):
             lib.mi_engine_destroy(self._h)
             self._h = None
+
+    __del__ = close
+
+
+class PinnedBuffer:
+    """Page-locked host memory (mi_host_alloc) exposed as a numpy uint8 array: what mi_engine_process_host moves by
+    DMA without a staging copy."""
+
+    def __init__(self, nbytes: int):
+        self._p = lib.mi_host_alloc(nbytes)
+        if not self._p:
+            raise UpsamplerError(last_error())
+        self.array = np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(self._p))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib.mi_host_free(self._p)
+            self._p = None
 
     __del__ = close
 

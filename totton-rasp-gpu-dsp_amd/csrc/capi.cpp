@@ -28,7 +28,6 @@ struct mi_ups {
   FilterConfig config{};
   std::shared_ptr<DeviceFilter> filter;
   std::unique_ptr<Engine> engine;
-  bool privateFilter = false;  // true once this handle forked its own tables (EQ)
 };
 
 namespace {
@@ -139,7 +138,6 @@ int mi_ups_load_filter(mi_ups *h, const char *json_path, int flags, char *err, s
         h->config = config;
         h->filter = std::move(filter);
         h->engine = std::move(engine);
-        h->privateFilter = true;
         h->initialized = true;
         CopyMessage("", err, errcap);
         return MI_OK;
@@ -213,14 +211,18 @@ int mi_ups_set_eq(mi_ups *h, const char *apo_text, double fs_out) {
           return Fail(MI_ERR_ARG, "not initialised");
         }
         std::string error;
-        if (h->filter.use_count() > 1) {
-          // clones share tables; an EQ change must stay private to this handle
-          auto own = h->filter->Fork(&error);
+        // the handle and its engine hold one reference each; more means clones share these tables, and an EQ change
+        // must stay private to this handle: build a private filter WITH the EQ (one table build, not two)
+        if (h->filter.use_count() > 2) {
+          auto own = h->filter->Fork(apo_text ? apo_text : "", fs_out, &error);
           if (!own) {
             return Fail(MI_ERR_DEVICE, error);
           }
+          if (!h->engine->Rebind(own, false, &error)) {
+            return Fail(MI_ERR_DEVICE, error);
+          }
           h->filter = own;
-          h->engine->Rebind(h->filter);
+          return MI_OK;
         }
         if (!h->filter->SetEq(apo_text ? apo_text : "", fs_out, &error)) {
           return Fail(MI_ERR_DEVICE, error);
@@ -405,6 +407,43 @@ int mi_engine_process_host(mi_engine *e, const void *h_in, size_t in_stream_stri
                    : Fail(MI_ERR_DEVICE, error);
       },
       MI_ERR_DEVICE);
+}
+
+void *mi_host_alloc(size_t bytes) {
+  return Guard(
+      [&]() -> void * {
+        std::string error;
+        void *p = miups::HostAlloc(bytes, &error);
+        if (!p) {
+          Fail(MI_ERR_DEVICE, error);
+        }
+        return p;
+      },
+      nullptr);
+}
+
+void mi_host_free(void *p) { miups::HostFree(p); }
+
+int mi_engine_rebind(mi_engine *e, mi_filter *f, int reset_history) {
+  return Guard(
+      [&]() -> int {
+        if (!e || !f) {
+          return Fail(MI_ERR_ARG, "null argument");
+        }
+        std::string error;
+        return e->engine->Rebind(f->filter, reset_history != 0, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+unsigned long long mi_filter_generation(const mi_filter *f) { return f ? f->filter->generation() : 0; }
+
+unsigned long long mi_engine_last_generation(const mi_engine *e) { return e ? e->engine->lastGeneration() : 0; }
+
+void mi_debug_fail_next_table_upload(mi_filter *f) {
+  if (f) {
+    f->filter->FailNextUploadForTest();
+  }
 }
 
 int mi_engine_enable_kernel_timing(mi_engine *e, int slots) {

@@ -69,17 +69,71 @@ MI_DEVICE cf mk(float x, float y) {
   r.y = y;
   return r;
 }
-MI_DEVICE cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-MI_DEVICE cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-MI_DEVICE cf cmul(cf a, cf b) {
-  return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+
+// ---- packed arithmetic ---------------------------------------------------------------------------------------
+// All butterfly arithmetic is written on `v2` = one complex value {re, im}, in a form that maps 1:1 onto gfx950's
+// packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on an aligned register pair; swizzles and
+// whole-vector negation ride on op_sel / neg modifiers; the one thing hipcc does not fold, a swizzle with ONE negated
+// half = the second step of a complex product, is a single inline-asm v_pk_fma_f32 -- hipcc pads the packed-result
+// forwarding hazard around asm statements itself).
+// Measured (profiles/r02_b_*): a packed instruction takes 0.72x the time of the two scalar ones it replaces when two
+// waves share a SIMD, the radix-16 passes drop from 523-629 to 289-395 VALU instructions, and in isolation the middle
+// passes get 7-12 % and the spectral stage 2x faster -- but the passes are then LDS-bound (2.05k cycles of LDS pipe
+// per pass), the aligned pairs cost 14 more spilled registers inside the phase loop, and the whole kernel is 5-6 %
+// SLOWER (config 2: 190 -> 179, config 5: 168 -> 163 Gsamples/s, same box, interleaved runs). The product therefore
+// compiles this source to scalar instructions; -DMIUPS_EXP_PACKED_MATH (experiment switch) selects the packed form.
+// The emulation build (g++, tests/emu) uses the scalar form too.
+#if defined(MIUPS_HOST_EMU) || defined(MIUPS_EXP_SCALAR_MATH)
+struct v2 {
+  float x, y;
+};
+MI_DEVICE v2 operator+(v2 a, v2 b) { return v2{a.x + b.x, a.y + b.y}; }
+MI_DEVICE v2 operator-(v2 a, v2 b) { return v2{a.x - b.x, a.y - b.y}; }
+MI_DEVICE v2 operator*(v2 a, v2 b) { return v2{a.x * b.x, a.y * b.y}; }
+MI_DEVICE v2 operator*(v2 a, float s) { return v2{a.x * s, a.y * s}; }
+MI_DEVICE v2 operator-(v2 a) { return v2{-a.x, -a.y}; }
+MI_DEVICE v2 v2swap(v2 a) { return v2{a.y, a.x}; }
+MI_DEVICE v2 v2xx(v2 a) { return v2{a.x, a.x}; }
+MI_DEVICE v2 v2yy(v2 a) { return v2{a.y, a.y}; }
+MI_DEVICE v2 v2fma(v2 a, v2 b, v2 c) { return v2{a.x * b.x + c.x, a.y * b.y + c.y}; }
+// (-a.y*w.y + t.x, a.x*w.y + t.y) and (a.y*w.y + t.x, -a.x*w.y + t.y)
+MI_DEVICE v2 v2cross(v2 a, v2 w, v2 t) { return v2{-a.y * w.y + t.x, a.x * w.y + t.y}; }
+MI_DEVICE v2 v2crossc(v2 a, v2 w, v2 t) { return v2{a.y * w.y + t.x, -a.x * w.y + t.y}; }
+#else
+typedef float v2 __attribute__((ext_vector_type(2)));
+MI_DEVICE v2 v2swap(v2 a) { return a.yx; }
+MI_DEVICE v2 v2xx(v2 a) { return a.xx; }
+MI_DEVICE v2 v2yy(v2 a) { return a.yy; }
+MI_DEVICE v2 v2fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+MI_DEVICE v2 v2cross(v2 a, v2 w, v2 t) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
 }
+MI_DEVICE v2 v2crossc(v2 a, v2 w, v2 t) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+#endif
+MI_DEVICE v2 V(cf a) { return v2{a.x, a.y}; }
+MI_DEVICE cf C(v2 a) { return mk(a.x, a.y); }
+MI_DEVICE v2 v2mk(float x, float y) { return v2{x, y}; }
+// a * w  and  a * conj(w): two packed instructions each
+MI_DEVICE v2 vmul(v2 a, v2 w) { return v2cross(a, w, a * v2xx(w)); }
+MI_DEVICE v2 vmulc(v2 a, v2 w) { return v2crossc(a, w, a * v2xx(w)); }
+// j*a and -j*a
+MI_DEVICE v2 vmulj(v2 a) { return v2swap(a) * v2mk(-1.0f, 1.0f); }
+MI_DEVICE v2 vmulnj(v2 a) { return v2swap(a) * v2mk(1.0f, -1.0f); }
+MI_DEVICE v2 vconj(v2 a) { return a * v2mk(1.0f, -1.0f); }
+
+MI_DEVICE cf cadd(cf a, cf b) { return C(V(a) + V(b)); }
+MI_DEVICE cf csub(cf a, cf b) { return C(V(a) - V(b)); }
+MI_DEVICE cf cmul(cf a, cf b) { return C(vmul(V(a), V(b))); }
 // a * conj(b)
-MI_DEVICE cf cmulc(cf a, cf b) {
-  return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
+MI_DEVICE cf cmulc(cf a, cf b) { return C(vmulc(V(a), V(b))); }
 MI_DEVICE cf cconj(cf a) { return mk(a.x, -a.y); }
-MI_DEVICE cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+MI_DEVICE cf cscale(cf a, float s) { return C(V(a) * s); }
 MI_DEVICE cf cneg(cf a) { return mk(-a.x, -a.y); }
 // j*a and -j*a
 MI_DEVICE cf cmulj(cf a) { return mk(-a.y, a.x); }

@@ -157,21 +157,24 @@ MI_DEVICE cf w64(int t) {
 
 // ---- mirror-pair algebra (see gen_multiply_kernel for the per-bin form) ---
 //   xa = (u+v) - jW(u-v), xb = (u+v) + jW(u-v),  v = conj(zm)
-MI_DEVICE void pair_split(cf u, cf zm, cf W, cf &xa, cf &xb) {
-  const cf v = cconj(zm);
-  const cf s = cadd(u, v);
-  const cf d = cmulj(cmul(W, csub(u, v)));
-  xa = csub(s, d);
-  xb = cadd(s, d);
+// packed: with c = (1,-1), v = zm*c, s = u+v, e = u-v, jW e = (W e).yx * (-1,1) -> folded into the two fma's
+MI_DEVICE void pair_split(cf u_, cf zm_, cf W_, cf &xa, cf &xb) {
+  const v2 u = V(u_), W = V(W_);
+  const v2 s = v2fma(V(zm_), v2mk(1.0f, -1.0f), u);   // u + conj(zm)
+  const v2 e = v2fma(V(zm_), v2mk(-1.0f, 1.0f), u);   // u - conj(zm)
+  const v2 d = v2swap(vmul(e, W));                    // (W e).yx ; j*(W e) = d * (-1, 1)
+  xa = C(v2fma(d, v2mk(1.0f, -1.0f), s));              // s - j W e
+  xb = C(v2fma(d, v2mk(-1.0f, 1.0f), s));              // s + j W e
 }
 //   P = xa*gs, Q = xb*gc ; zk = (P+Q) + j conj(W)(P-Q) ; zkm = conj((P+Q) - j conj(W)(P-Q))
-MI_DEVICE void pair_phase(cf xa, cf xb, cf W, f4 g, cf &zk, cf &zkm) {
-  const cf P = cmul(xa, mk(g.x, g.y));
-  const cf Q = cmul(xb, mk(g.z, g.w));
-  const cf S = cadd(P, Q);
-  const cf D = cmulj(cmulc(csub(P, Q), W));
-  zk = cadd(S, D);
-  zkm = cconj(csub(S, D));
+MI_DEVICE void pair_phase(cf xa, cf xb, cf W_, f4 g, cf &zk, cf &zkm) {
+  const v2 P = vmul(V(xa), v2mk(g.x, g.y));
+  const v2 Q = vmul(V(xb), v2mk(g.z, g.w));
+  const v2 S = P + Q;
+  const v2 d = v2swap(vmulc(P - Q, V(W_)));           // (conj(W)(P-Q)).yx ; j*(..) = d * (-1, 1)
+  zk = C(v2fma(d, v2mk(-1.0f, 1.0f), S));              // S + j conj(W)(P-Q)
+  // conj(S - j conj(W)(P-Q)) = (S - D)*(1,-1), D = d*(-1,1):  S*(1,-1) + d*(1,1)... = S*(1,-1) + d
+  zkm = C(v2fma(S, v2mk(1.0f, -1.0f), d));
 }
 
 // ---- format-typed sample load (p points AT the sample) ----------------------
@@ -487,7 +490,7 @@ struct FusedKernel {
     lds_get<16, S>(lds, bA, A);
     lds_get<16, S>(lds, bB, B);
     if constexpr (T % S == 0) {  // both butterflies use the same twiddle: one power tree (-9 % VALU in this pass)
-      cf tw16[15];
+      Tw16 tw16;
       make_twiddles16<-1>(wA, tw16);
       dft16<-1>(A);
       mul_twiddles16_out(A, tw16);
@@ -537,7 +540,7 @@ struct FusedKernel {
     lds_get<16, S>(lds, bA, A);
     lds_get<16, S>(lds, bB, B);
     if constexpr (T % S == 0) {
-      cf tw16[15];
+      Tw16 tw16;
       make_twiddles16<+1>(wA, tw16);
       mul_twiddles16(A, tw16);
       dft16<+1>(A);
@@ -1337,8 +1340,11 @@ struct FusedKernel {
 
 // EXT = false: whole-frame groups, frames written by the kernel's own epilogue;
 // EXT = true: io.ext_epilogue, the kernel stops at the staging planes (see channel_block).
+// Launch bounds: at least two waves per SIMD, i.e. at most 256 registers per lane, for every size. (With "1" hipcc
+// parks 9-18 values of the K <= 8192 kernels in AGPRs instead of spilling them: 272 registers, ONE wave per SIMD, and a
+// lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5: profiles/r02_a_ubench_valu_lds_rates.txt.)
 template <int LOG2K, bool EXT>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_kernel(Geometry g,
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 2) void fused_kernel(Geometry g,
                                                                                                       IoDesc io,
                                                                                                       FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
@@ -1348,7 +1354,7 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 
 // Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see
 // FusedKernel::channel_block_split. Same launch shape and LDS as fused_kernel<LOG2K>.
 template <int LOG2K>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 1) void fused_split_kernel(Geometry g,
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 2) void fused_split_kernel(Geometry g,
                                                                                                             IoDesc io,
                                                                                                             FusedTables ft) {
   MI_DYN_SHARED(cf, lds);

@@ -4,7 +4,9 @@
 #pragma once
 
 #include <complex>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -20,45 +22,64 @@ const std::string &LastError();
 
 int DeviceCount();
 
-// Device-resident, immutable-between-reloads filter state shared by engines.
+// One immutable set of device tables = one (filter, EQ) state. Engines take a snapshot per call and keep it alive until
+// the work they enqueued with it has finished, so an EQ change never frees or rewrites memory a running kernel reads:
+// it fills ANOTHER set (a pooled one when a retired set of the same shape is free, else a new allocation), uploads it on
+// a private stream and swaps the filter's pointer. No device-wide synchronisation, no stall of the audio streams; the
+// first block enqueued after the swap uses the new spectrum (reference: RELOAD semantics of web/routers/eq.py:220-249,
+// src/zmq/zmq_server_main.cpp:168-172 -- the data plane there has no call site).
+struct TableSet {
+  int device = 0;
+  unsigned long long generation = 0;
+  cf *Gs = nullptr, *Gc = nullptr, *Wm = nullptr, *tw = nullptr, *WmT = nullptr, *selfW = nullptr;
+  int *blockB = nullptr;
+  f4 *GT = nullptr, *G0 = nullptr;
+  cf wb{1.0f, 0.0f};
+  std::size_t count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // elements per array (pool reuse needs the same shape)
+  FusedTables fused() const { return FusedTables{tw, WmT, blockB, GT, G0, wb, selfW}; }
+  ~TableSet();
+};
+struct TablePool;  // retired sets of one filter, free for reuse
+
+// Device-resident filter state shared by engines.
 class DeviceFilter {
  public:
   ~DeviceFilter();
   static std::shared_ptr<DeviceFilter> Create(int device, const FilterConfig &config, std::vector<float> taps,
-                                              int flags, std::string *error);
-  // Rebuild the tables with (or without, when text is empty) the EQ folded in.
+                                              int flags, std::string *error, const std::string &apoText = std::string(),
+                                              double fsOut = 0.0);
+  // Swap in tables with (or without, when text is empty) the EQ folded in. On failure the current tables stay.
   bool SetEq(const std::string &apoText, double fsOut, std::string *error);
-  // A private copy with its own tables (used when one handle changes its EQ).
-  std::shared_ptr<DeviceFilter> Fork(std::string *error) const;
+  // A private copy with its own tables and EQ (used when one handle of several changes its EQ; empty text = no EQ).
+  std::shared_ptr<DeviceFilter> Fork(const std::string &apoText, double fsOut, std::string *error) const;
 
   int device() const { return device_; }
   const FilterConfig &config() const { return config_; }
-  const Geometry &geometry() const { return geo_; }
-  const cf *Gs() const { return dGs_; }
-  const cf *Gc() const { return dGc_; }
-  const cf *Wm() const { return dWm_; }
-  const cf *tw() const { return dtw_; }
+  const Geometry &geometry() const { return geo_; }  // fixed by the filter file; an EQ change never alters it
   bool hasFused() const { return hasFused_; }
   bool fusedSplit() const { return fusedSplit_; }  // tables are laid out for fused_split_kernel
-  FusedTables fused() const { return FusedTables{dtw_, dWmT_, dBlockB_, dGT_, dG0_, wb_, dSelfW_}; }
+  // current tables; the caller keeps the pointer for as long as enqueued work may read them
+  std::shared_ptr<const TableSet> tables() const;
+  unsigned long long generation() const;  // bumped by every successful SetEq
+  // test hook: make the next table upload fail after the host-side build (a failed swap must leave the filter usable)
+  void FailNextUploadForTest() { failNextUpload_ = true; }
 
  private:
   DeviceFilter() = default;
   bool Rebuild(const std::vector<std::complex<double>> *eqHalf, std::string *error);
-  void Free();
 
   int device_ = 0;
   FilterConfig config_{};
   std::vector<float> taps_;
   int flags_ = 0;
   Geometry geo_{};
-  cf *dGs_ = nullptr, *dGc_ = nullptr, *dWm_ = nullptr, *dtw_ = nullptr;
-  // fused-kernel layout of the same spectra (FusedTables)
   bool hasFused_ = false, fusedSplit_ = false;
-  cf *dWmT_ = nullptr, *dSelfW_ = nullptr;
-  int *dBlockB_ = nullptr;
-  f4 *dGT_ = nullptr, *dG0_ = nullptr;
-  cf wb_{1.0f, 0.0f};
+  mutable std::mutex mu_;
+  std::shared_ptr<const TableSet> cur_;
+  std::shared_ptr<TablePool> pool_;
+  unsigned long long generation_ = 0;
+  void *uploadStream_ = nullptr;  // hipStream_t, non-blocking: uploads never order against the audio streams
+  bool failNextUpload_ = false;
 };
 
 // Evaluate an APO profile's cascade on the device: bins 0..numBins-1 (fp64).
@@ -70,12 +91,20 @@ class Engine {
   ~Engine();
   static std::unique_ptr<Engine> Create(std::shared_ptr<DeviceFilter> filter, int streams, int channels, int inFmt,
                                         int outFmt, std::string *error);
-  std::unique_ptr<Engine> Clone(std::string *error) const;  // deep copy of the history
-  void Rebind(std::shared_ptr<DeviceFilter> filter) { filter_ = std::move(filter); }
+  std::unique_ptr<Engine> Clone(std::string *error);  // deep copy of the history (after everything enqueued so far)
+  // Switch to another filter of the SAME geometry class between blocks (rate-family / phase switching with resident
+  // spectra, EQ forks). The history is input-domain, so it carries over when the history length matches; otherwise
+  // (or with resetHistory) it is zeroed, as after LoadFilter in the reference.
+  bool Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std::string *error);
 
   bool Reset(std::string *error);
+  // Stream contract: all state of an engine (history, staging planes) is ordered by the engine itself. Calls may use
+  // different streams: a call on another stream than the previous one first waits (hipStreamWaitEvent) for the
+  // previous call's work. One engine must not be entered from two host threads at once.
   bool ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, std::size_t outStride, std::size_t blocks,
                      void *hipStream, std::string *error);
+  // Host buffers: H2D / kernels / D2H of consecutive sub-batches overlap on three streams through double-buffered
+  // device staging. Pinned host memory (mi_host_alloc) is copied by DMA directly; pageable memory works, slower.
   bool ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std::size_t outStride, std::size_t blocks,
                    std::string *error);
 
@@ -91,11 +120,18 @@ class Engine {
   double LastKernelMs();
   // average/min/max over the recorded calls since EnableTiming (waits for them)
   bool KernelMsStats(double *avg, double *mn, double *mx, int *count);
+  // generation of the filter tables the most recent ProcessDevice call used
+  unsigned long long lastGeneration() const { return lastGeneration_; }
 
  private:
   Engine() = default;
   bool EnsureWork(std::size_t items, std::string *error);
   void PickChannelGroup(std::size_t blocks);
+  bool EnsureStreams(std::string *error);
+  void *TakeEvent();                       // hipEvent_t from the pool
+  void Reap(bool all);                     // release table snapshots of finished calls
+  bool OrderAfterLast(void *stream, std::string *error);
+  bool MarkDone(void *stream, std::shared_ptr<const TableSet> tabs, std::string *error);
 
   std::shared_ptr<DeviceFilter> filter_;
   int streams_ = 1, channels_ = 1, inFmt_ = kF32, outFmt_ = kF32;
@@ -103,7 +139,7 @@ class Engine {
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
   std::size_t wgCapacity_ = 256;   // fused path: workgroups resident on the whole chip at once
-  float *scratch_ = nullptr;       // fused path: fp32 staging planes
+  float *scratch_ = nullptr;       // fused path: fp32 staging planes (two halves when launches are pipelined)
   std::size_t scratchBytes_ = 0;
   float *planar_ = nullptr;        // fused path, > 2 channels: per-channel fp32 timelines (planarize_kernel)
   std::size_t planarBytes_ = 0;
@@ -113,12 +149,31 @@ class Engine {
   // staged-path work arrays
   cf *work_[4] = {nullptr, nullptr, nullptr, nullptr};
   std::size_t workItems_ = 0;
-  // host-buffer staging
-  void *stageIn_ = nullptr, *stageOut_ = nullptr;
+  // host-buffer staging: two device slots per direction
+  void *stageIn_[2] = {nullptr, nullptr}, *stageOut_[2] = {nullptr, nullptr};
   std::size_t stageInBytes_ = 0, stageOutBytes_ = 0;
+  // engine-owned streams: own_ (Reset/Clone/ProcessHost kernels), aux_ (interleave kernels of the pipelined
+  // launches), h2d_/d2h_ (ProcessHost copies)
+  void *own_ = nullptr, *aux_ = nullptr, *h2d_ = nullptr, *d2h_ = nullptr;
+  // ordering + table lifetime: one event per call, newest last
+  struct InFlight {
+    void *done;
+    void *stream;
+    std::shared_ptr<const TableSet> tabs;
+  };
+  std::deque<InFlight> inflight_;
+  std::vector<void *> eventPool_;
+  // events of the pipelines: [0..1] transform kernel of a plane buffer done, [2..3] its frames written,
+  // [4..5] host input slot copied in, [6..7] its kernels done, [8..9] its output copied out
+  void *pipeEv_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long lastGeneration_ = 0;
   // timing
   std::vector<void *> evStart_, evStop_;
   long long evCount_ = 0;
 };
+
+// Pinned host memory for ProcessHost callers (hipHostMalloc / hipHostFree).
+void *HostAlloc(std::size_t bytes, std::string *error);
+void HostFree(void *p);
 
 }  // namespace miups

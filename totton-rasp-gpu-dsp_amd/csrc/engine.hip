@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
+#include <initializer_list>
 #include <cstring>
 #include <sstream>
 
@@ -140,7 +142,7 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
 }
 
 template <int LOG2K, bool EXT>
-bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
                         std::string *error) {
   using Cfg = FusedCfg<LOG2K>;
   static bool attr_set[64] = {};
@@ -151,19 +153,19 @@ bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const DeviceFilter 
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, f.fused());
+  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, ft);
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
 }
 
 template <int LOG2K>
-bool LaunchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+bool LaunchFused(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
                  std::string *error) {
-  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true>(g, io, f, items, st, error)
-                         : LaunchFusedVariant<LOG2K, false>(g, io, f, items, st, error);
+  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true>(g, io, ft, items, st, error)
+                         : LaunchFusedVariant<LOG2K, false>(g, io, ft, items, st, error);
 }
 
 template <int LOG2K>
-bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
+bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
                       std::string *error) {
   using Cfg = FusedCfg<LOG2K>;
   static bool attr_set[64] = {};
@@ -174,44 +176,56 @@ bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const DeviceFilter &f
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES_SPLIT));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io,
-                     f.fused());
+  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io, ft);
   return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
 }
 
-bool DispatchFused(const Geometry &g, const IoDesc &io, const DeviceFilter &f, unsigned items, hipStream_t st,
-                   std::string *error) {
-  if (f.fusedSplit()) {
+bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, unsigned items,
+                   hipStream_t st, std::string *error) {
+  if (split) {
     // block transform length K = 32768: two 16384-point transforms through the LDS
     // (the split layout is only built for that size outside the emulation tests)
+#if !defined(MIUPS_ONLY_LOG2K) || MIUPS_ONLY_LOG2K == 15
     if (g.log2k == 15) {
       return LaunchFusedSplit<14>(g, io, f, items, st, error);
     }
-    if (g.log2k == 14) {  // experiment switch MIUPS_EXP_FORCE_SPLIT (profiles/): two 64 KiB workgroups per CU
-      return LaunchFusedSplit<13>(g, io, f, items, st, error);
-    }
+#endif
     if (error) {
       *error = "split fused kernel does not cover this geometry";
     }
     return false;
   }
   switch (g.log2k) {
-    case 5: return LaunchFused<5>(g, io, f, items, st, error);
-    case 6: return LaunchFused<6>(g, io, f, items, st, error);
-    case 7: return LaunchFused<7>(g, io, f, items, st, error);
-    case 8: return LaunchFused<8>(g, io, f, items, st, error);
-    case 9: return LaunchFused<9>(g, io, f, items, st, error);
-    case 10: return LaunchFused<10>(g, io, f, items, st, error);
-    case 11: return LaunchFused<11>(g, io, f, items, st, error);
-    case 12: return LaunchFused<12>(g, io, f, items, st, error);
-    case 13: return LaunchFused<13>(g, io, f, items, st, error);
-    case 14: return LaunchFused<14>(g, io, f, items, st, error);
+// MIUPS_ONLY_LOG2K=n (scripts/build_variant.sh): experiment builds instantiate one transform length only (seconds, not minutes)
+#if !defined(MIUPS_ONLY_LOG2K)
+#define MI_FUSED_CASE(n) \
+  case n: return LaunchFused<n>(g, io, f, items, st, error);
+#else
+#define MI_FUSED_CASE(n)                                     \
+  case n:                                                    \
+    if constexpr (n == MIUPS_ONLY_LOG2K) {                   \
+      return LaunchFused<n>(g, io, f, items, st, error);     \
+    }                                                        \
+    break;
+#endif
+    MI_FUSED_CASE(5)
+    MI_FUSED_CASE(6)
+    MI_FUSED_CASE(7)
+    MI_FUSED_CASE(8)
+    MI_FUSED_CASE(9)
+    MI_FUSED_CASE(10)
+    MI_FUSED_CASE(11)
+    MI_FUSED_CASE(12)
+    MI_FUSED_CASE(13)
+    MI_FUSED_CASE(14)
+#undef MI_FUSED_CASE
     default:
-      if (error) {
-        *error = "fused kernel does not cover this geometry";
-      }
-      return false;
+      break;
   }
+  if (error) {
+    *error = "fused kernel does not cover this geometry";
+  }
+  return false;
 }
 
 // The fused kernel addresses samples with 32-bit byte offsets from per-block bases.
@@ -237,32 +251,85 @@ int DeviceCount() {
   return n;
 }
 
-// ------------------------------------------------------------ DeviceFilter --
-DeviceFilter::~DeviceFilter() { Free(); }
-
-void DeviceFilter::Free() {
-  if (dGs_ || dGc_ || dWm_ || dtw_) {
-    (void)hipSetDevice(device_);
+// ------------------------------------------------------------ TableSet / pool --
+TableSet::~TableSet() {
+  if (Gs || Gc || Wm || tw || WmT || selfW || blockB || GT || G0) {
+    (void)hipSetDevice(device);
   }
-  (void)hipFree(dGs_);
-  (void)hipFree(dGc_);
-  (void)hipFree(dWm_);
-  (void)hipFree(dtw_);
-  (void)hipFree(dWmT_);
-  (void)hipFree(dBlockB_);
-  (void)hipFree(dGT_);
-  (void)hipFree(dG0_);
-  (void)hipFree(dSelfW_);
-  dSelfW_ = nullptr;
-  dGs_ = dGc_ = dWm_ = dtw_ = dWmT_ = nullptr;
-  dBlockB_ = nullptr;
-  dGT_ = dG0_ = nullptr;
-  hasFused_ = false;
-  fusedSplit_ = false;
+  (void)hipFree(Gs);
+  (void)hipFree(Gc);
+  (void)hipFree(Wm);
+  (void)hipFree(tw);
+  (void)hipFree(WmT);
+  (void)hipFree(selfW);
+  (void)hipFree(blockB);
+  (void)hipFree(GT);
+  (void)hipFree(G0);
+}
+
+struct TablePool {
+  std::mutex mu;
+  std::vector<TableSet *> free;
+  ~TablePool() {
+    for (TableSet *t : free) {
+      delete t;
+    }
+  }
+};
+
+namespace {
+
+// shared_ptr deleter of a published table set: the last reference (filter or engine snapshot) has gone, so no
+// enqueued work reads the arrays any more -- park the set for the next EQ change instead of freeing it (hipFree
+// synchronises the device).
+struct PoolReturn {
+  std::weak_ptr<TablePool> pool;
+  void operator()(const TableSet *t) const {
+    TableSet *m = const_cast<TableSet *>(t);
+    if (std::shared_ptr<TablePool> p = pool.lock()) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      if (p->free.size() < 4) {
+        p->free.push_back(m);
+        return;
+      }
+    }
+    delete m;
+  }
+};
+
+template <typename T>
+bool FillArray(T **dst, std::size_t *count, const std::vector<T> &src, hipStream_t st, std::string *error) {
+  const std::size_t n = std::max<std::size_t>(src.size(), 1);
+  if (!*dst || *count != n) {
+    (void)hipFree(*dst);
+    *dst = nullptr;
+    *count = 0;
+    MI_HIP(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
+    *count = n;
+  }
+  if (!src.empty()) {
+    MI_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------ DeviceFilter --
+DeviceFilter::~DeviceFilter() {
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    cur_.reset();
+  }
+  if (uploadStream_) {
+    (void)hipSetDevice(device_);
+    (void)hipStreamDestroy(static_cast<hipStream_t>(uploadStream_));
+  }
 }
 
 std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfig &config, std::vector<float> taps,
-                                                   int flags, std::string *error) {
+                                                   int flags, std::string *error, const std::string &apoText,
+                                                   double fsOut) {
   if (!UseDevice(device, error)) {
     return nullptr;
   }
@@ -271,19 +338,29 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
   f->config_ = config;
   f->taps_ = std::move(taps);
   f->flags_ = flags & kLoadRefCompatSpectrum;  // the only load flag of the public boundary
-  if (config.fftSize / (2 * std::max<std::size_t>(config.upsampleFactor, 1)) == 16384 && std::getenv("MIUPS_EXP_FORCE_SPLIT")) {
-    f->flags_ |= kLoadInternalForceSplit;  // experiment switch (profiles/): K = 16384 as two 8192-point halves
-  }
-  if (!f->Rebuild(nullptr, error)) {
+  f->pool_ = std::make_shared<TablePool>();
+  if (!f->SetEq(apoText, fsOut, error)) {  // empty text: the plain filter
     return nullptr;
   }
   return f;
 }
 
-std::shared_ptr<DeviceFilter> DeviceFilter::Fork(std::string *error) const {
-  return Create(device_, config_, taps_, flags_, error);
+std::shared_ptr<DeviceFilter> DeviceFilter::Fork(const std::string &apoText, double fsOut, std::string *error) const {
+  return Create(device_, config_, taps_, flags_, error, apoText, fsOut);
 }
 
+std::shared_ptr<const TableSet> DeviceFilter::tables() const {
+  std::lock_guard<std::mutex> lock(mu_);
+  return cur_;
+}
+
+unsigned long long DeviceFilter::generation() const {
+  std::lock_guard<std::mutex> lock(mu_);
+  return generation_;
+}
+
+// Build the new tables on the host, upload them into a set that nothing reads, then publish it. Whatever fails on
+// the way, the published set is untouched: engines keep running on the old spectrum and the error is returned.
 bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std::string *error) {
   FilterTables t;
   if (!BuildTables(config_, taps_, eqHalf, flags_, &t, error)) {
@@ -292,23 +369,59 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
   if (!UseDevice(device_, error)) {
     return false;
   }
-  // tables may be in use by enqueued work of any engine sharing this filter
-  MI_HIP(hipDeviceSynchronize());
-  Free();
-  geo_ = t.geo;
-  if (!(Upload(t.Gs, &dGs_, error) && Upload(t.Gc, &dGc_, error) && Upload(t.Wm, &dWm_, error) &&
-        Upload(t.tw, &dtw_, error))) {
-    return false;
+  if (!uploadStream_) {
+    hipStream_t st = nullptr;
+    MI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    uploadStream_ = st;
   }
-  if (t.hasFused) {
-    if (!(Upload(t.WmT, &dWmT_, error) && Upload(t.blockB, &dBlockB_, error) && Upload(t.GT, &dGT_, error) &&
-          Upload(t.G0, &dG0_, error) && Upload(t.selfW, &dSelfW_, error))) {
-      return false;
+  hipStream_t up = static_cast<hipStream_t>(uploadStream_);
+  const std::size_t want[9] = {t.Gs.size(), t.Gc.size(), t.Wm.size(), t.tw.size(), t.WmT.size(),
+                               t.selfW.size(), t.blockB.size(), t.GT.size(), t.G0.size()};
+  std::unique_ptr<TableSet> set;
+  {
+    std::lock_guard<std::mutex> lock(pool_->mu);
+    for (std::size_t i = 0; i < pool_->free.size(); ++i) {
+      bool same = true;
+      for (int k = 0; k < 9; ++k) {
+        same = same && pool_->free[i]->count[k] == std::max<std::size_t>(want[k], 1);
+      }
+      if (same) {
+        set.reset(pool_->free[i]);
+        pool_->free.erase(pool_->free.begin() + static_cast<std::ptrdiff_t>(i));
+        break;
+      }
     }
-    wb_ = t.Wb;
-    hasFused_ = true;
+  }
+  if (!set) {
+    set.reset(new TableSet());
+  }
+  set->device = device_;
+  bool ok = FillArray(&set->Gs, &set->count[0], t.Gs, up, error) && FillArray(&set->Gc, &set->count[1], t.Gc, up, error) &&
+            FillArray(&set->Wm, &set->count[2], t.Wm, up, error) && FillArray(&set->tw, &set->count[3], t.tw, up, error) &&
+            FillArray(&set->WmT, &set->count[4], t.WmT, up, error) &&
+            FillArray(&set->selfW, &set->count[5], t.selfW, up, error) &&
+            FillArray(&set->blockB, &set->count[6], t.blockB, up, error) &&
+            FillArray(&set->GT, &set->count[7], t.GT, up, error) && FillArray(&set->G0, &set->count[8], t.G0, up, error);
+  if (ok && failNextUpload_) {
+    failNextUpload_ = false;
+    ok = false;
+    if (error) {
+      *error = "table upload failed (injected by test hook)";
+    }
+  }
+  // the host vectors must outlive the copies, and the set must be complete before anyone can see it
+  if (!HipOk(hipStreamSynchronize(up), "hipStreamSynchronize(upload)", ok ? error : nullptr) || !ok) {
+    return false;  // `set` is freed here; cur_ is unchanged
+  }
+  set->wb = t.Wb;
+  std::lock_guard<std::mutex> lock(mu_);
+  if (!cur_) {
+    geo_ = t.geo;
+    hasFused_ = t.hasFused;
     fusedSplit_ = t.fusedSplit;
   }
+  set->generation = ++generation_;
+  cur_ = std::shared_ptr<const TableSet>(set.release(), PoolReturn{pool_});
   return true;
 }
 
@@ -337,18 +450,36 @@ bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBin
   eq::EqProfile profile;
   eq::parseEqString(apoText, profile);  // an empty profile evaluates to unity, as in the reference
   const eq::Cascade cascade = eq::buildCascade(profile, fsOut);
+  // Everything on a private non-blocking stream with stream-ordered allocations: an EQ change while audio is
+  // streaming must neither join the NULL stream (which orders against every blocking stream) nor hipFree (which
+  // synchronises the device).
+  hipStream_t st = nullptr;
+  MI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   eq::BiquadCoeffs *dSec = nullptr;
   double2 *dOut = nullptr;
   const std::size_t nsec = cascade.sections.size();
-  MI_HIP(hipMalloc(reinterpret_cast<void **>(&dSec), std::max<std::size_t>(nsec, 1) * sizeof(eq::BiquadCoeffs)));
-  bool ok = HipOk(hipMalloc(reinterpret_cast<void **>(&dOut), numBins * sizeof(double2)), "hipMalloc", error);
+  bool pooled = true;
+  bool ok = true;
+  if (hipMallocAsync(reinterpret_cast<void **>(&dSec), std::max<std::size_t>(nsec, 1) * sizeof(eq::BiquadCoeffs), st) !=
+          hipSuccess ||
+      hipMallocAsync(reinterpret_cast<void **>(&dOut), numBins * sizeof(double2), st) != hipSuccess) {
+    (void)hipGetLastError();
+    if (dSec) {
+      (void)hipFreeAsync(dSec, st);
+      dSec = nullptr;
+    }
+    pooled = false;  // no stream-ordered allocator on this runtime: plain allocations
+    ok = HipOk(hipMalloc(reinterpret_cast<void **>(&dSec), std::max<std::size_t>(nsec, 1) * sizeof(eq::BiquadCoeffs)),
+               "hipMalloc", error) &&
+         HipOk(hipMalloc(reinterpret_cast<void **>(&dOut), numBins * sizeof(double2)), "hipMalloc", error);
+  }
   if (ok && nsec) {
-    ok = HipOk(hipMemcpy(dSec, cascade.sections.data(), nsec * sizeof(eq::BiquadCoeffs), hipMemcpyHostToDevice),
-               "hipMemcpy", error);
+    ok = HipOk(hipMemcpyAsync(dSec, cascade.sections.data(), nsec * sizeof(eq::BiquadCoeffs), hipMemcpyHostToDevice, st),
+               "hipMemcpyAsync", error);
   }
   if (ok) {
     const double df = fsOut / static_cast<double>(fullFft);
-    hipLaunchKernelGGL(eq_response_kernel, dim3(Blocks(static_cast<long long>(numBins), 256)), dim3(256), 0, 0,
+    hipLaunchKernelGGL(eq_response_kernel, dim3(Blocks(static_cast<long long>(numBins), 256)), dim3(256), 0, st,
                        cascade.preampLinear, profile.preampDb != 0.0 ? 1 : 0, dSec, static_cast<int>(nsec), fsOut, df,
                        numBins, dOut);
     ok = HipOk(hipGetLastError(), "eq_response_kernel", error);
@@ -356,10 +487,19 @@ bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBin
   if (ok) {
     out->resize(numBins);
     static_assert(sizeof(std::complex<double>) == sizeof(double2), "layout");
-    ok = HipOk(hipMemcpy(out->data(), dOut, numBins * sizeof(double2), hipMemcpyDeviceToHost), "hipMemcpy", error);
+    ok = HipOk(hipMemcpyAsync(out->data(), dOut, numBins * sizeof(double2), hipMemcpyDeviceToHost, st), "hipMemcpyAsync",
+               error);
   }
-  (void)hipFree(dSec);
-  (void)hipFree(dOut);
+  if (pooled) {
+    (void)hipFreeAsync(dSec, st);
+    (void)hipFreeAsync(dOut, st);
+  }
+  ok = HipOk(hipStreamSynchronize(st), "hipStreamSynchronize(eq)", ok ? error : nullptr) && ok;
+  if (!pooled) {
+    (void)hipFree(dSec);
+    (void)hipFree(dOut);
+  }
+  (void)hipStreamDestroy(st);
   return ok;
 }
 
@@ -368,15 +508,32 @@ Engine::~Engine() {
   if (filter_) {
     (void)hipSetDevice(filter_->device());
   }
+  Reap(true);  // every enqueued call has finished before its buffers go
+  for (void *st : {own_, aux_, h2d_, d2h_}) {
+    if (st) {
+      (void)hipStreamSynchronize(static_cast<hipStream_t>(st));
+      (void)hipStreamDestroy(static_cast<hipStream_t>(st));
+    }
+  }
   (void)hipFree(hist_[0]);
   (void)hipFree(hist_[1]);
   for (auto *w : work_) {
     (void)hipFree(w);
   }
-  (void)hipFree(stageIn_);
-  (void)hipFree(stageOut_);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(stageIn_[i]);
+    (void)hipFree(stageOut_[i]);
+  }
   (void)hipFree(scratch_);
   (void)hipFree(planar_);
+  for (void *e : eventPool_) {
+    (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  }
+  for (void *e : pipeEv_) {
+    if (e) {
+      (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    }
+  }
   for (void *e : evStart_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -423,24 +580,113 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   e->cuCount_ = cus;
   e->histStride_ = static_cast<std::size_t>(g.hist_frames) * channels * pcm_bytes(inFmt);
   const std::size_t bytes = std::max<std::size_t>(e->histStride_ * streams, 16);
+  if (!e->EnsureStreams(error)) {
+    return nullptr;
+  }
+  hipStream_t own = static_cast<hipStream_t>(e->own_);
   for (int i = 0; i < 2; ++i) {
     if (!HipOk(hipMalloc(&e->hist_[i], bytes), "hipMalloc(history)", error) ||
-        !HipOk(hipMemset(e->hist_[i], 0, bytes), "hipMemset(history)", error)) {
+        !HipOk(hipMemsetAsync(e->hist_[i], 0, bytes, own), "hipMemset(history)", error)) {
       return nullptr;
     }
+  }
+  if (!e->MarkDone(own, nullptr, error)) {
+    return nullptr;
   }
   return e;
 }
 
-std::unique_ptr<Engine> Engine::Clone(std::string *error) const {
+bool Engine::EnsureStreams(std::string *error) {
+  for (void **slot : {&own_, &aux_, &h2d_, &d2h_}) {
+    if (!*slot) {
+      hipStream_t st = nullptr;
+      MI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      *slot = st;
+    }
+  }
+  for (void *&e : pipeEv_) {
+    if (!e) {
+      hipEvent_t ev = nullptr;
+      MI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e = ev;
+    }
+  }
+  return true;
+}
+
+void *Engine::TakeEvent() {
+  if (!eventPool_.empty()) {
+    void *e = eventPool_.back();
+    eventPool_.pop_back();
+    return e;
+  }
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    return nullptr;
+  }
+  return ev;
+}
+
+// Drop the table snapshots (and recycle the events) of calls that have finished.
+void Engine::Reap(bool all) {
+  while (!inflight_.empty()) {
+    InFlight &f = inflight_.front();
+    if (all) {
+      (void)hipEventSynchronize(static_cast<hipEvent_t>(f.done));
+    } else if (hipEventQuery(static_cast<hipEvent_t>(f.done)) != hipSuccess) {
+      (void)hipGetLastError();  // hipErrorNotReady is not an error
+      break;
+    }
+    eventPool_.push_back(f.done);
+    inflight_.pop_front();
+  }
+}
+
+// All engine state is ordered by the chain of per-call events: work on `stream` starts after the previous call's
+// work, whichever stream that ran on.
+bool Engine::OrderAfterLast(void *stream, std::string *error) {
+  Reap(false);
+  if (!inflight_.empty() && inflight_.back().stream != stream) {
+    MI_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(inflight_.back().done), 0));
+  }
+  return true;
+}
+
+bool Engine::MarkDone(void *stream, std::shared_ptr<const TableSet> tabs, std::string *error) {
+  void *ev = TakeEvent();
+  if (!ev) {
+    if (error) {
+      *error = "hipEventCreate failed";
+    }
+    return false;
+  }
+  if (!HipOk(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)), "hipEventRecord", error)) {
+    eventPool_.push_back(ev);
+    return false;
+  }
+  inflight_.push_back(InFlight{ev, stream, std::move(tabs)});
+  while (inflight_.size() > 64) {  // a caller that never synchronises: bound the queue
+    (void)hipEventSynchronize(static_cast<hipEvent_t>(inflight_.front().done));
+    eventPool_.push_back(inflight_.front().done);
+    inflight_.pop_front();
+  }
+  return true;
+}
+
+std::unique_ptr<Engine> Engine::Clone(std::string *error) {
   auto e = Create(filter_, streams_, channels_, inFmt_, outFmt_, error);
   if (!e) {
     return nullptr;
   }
   const std::size_t bytes = histStride_ * streams_;
   if (bytes) {
-    // default-stream copy: ordered after every earlier enqueue on that stream
-    if (!HipOk(hipMemcpy(e->hist_[e->cur_], hist_[cur_], bytes, hipMemcpyDeviceToDevice), "hipMemcpy(history)", error)) {
+    // on this engine's own stream, after everything enqueued so far on whatever stream; the clone is usable on return
+    hipStream_t own = static_cast<hipStream_t>(own_);
+    if (!OrderAfterLast(own_, error) ||
+        !HipOk(hipStreamSynchronize(static_cast<hipStream_t>(e->own_)), "hipStreamSynchronize", error) ||
+        !HipOk(hipMemcpyAsync(e->hist_[e->cur_], hist_[cur_], bytes, hipMemcpyDeviceToDevice, own), "hipMemcpy(history)",
+               error) ||
+        !MarkDone(own_, nullptr, error) || !HipOk(hipStreamSynchronize(own), "hipStreamSynchronize", error)) {
       return nullptr;
     }
   }
@@ -452,9 +698,45 @@ bool Engine::Reset(std::string *error) {
     return false;
   }
   const std::size_t bytes = std::max<std::size_t>(histStride_ * streams_, 16);
-  MI_HIP(hipDeviceSynchronize());
-  MI_HIP(hipMemset(hist_[0], 0, bytes));
-  MI_HIP(hipMemset(hist_[1], 0, bytes));
+  hipStream_t own = static_cast<hipStream_t>(own_);
+  if (!OrderAfterLast(own_, error)) {
+    return false;
+  }
+  MI_HIP(hipMemsetAsync(hist_[0], 0, bytes, own));
+  MI_HIP(hipMemsetAsync(hist_[1], 0, bytes, own));
+  return MarkDone(own_, nullptr, error);
+}
+
+bool Engine::Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std::string *error) {
+  if (!filter || filter->device() != filter_->device()) {
+    if (error) {
+      *error = "Rebind: the new filter must live on the engine's device";
+    }
+    return false;
+  }
+  if (!UseDevice(filter->device(), error)) {
+    return false;
+  }
+  const Geometry &g = filter->geometry();
+  const std::size_t stride = static_cast<std::size_t>(g.hist_frames) * channels_ * pcm_bytes(inFmt_);
+  const bool sameHistory = stride == histStride_;
+  // the history is raw input frames: it stays valid under another filter of the same history length
+  if (!sameHistory) {
+    Reap(true);  // buffers of the old size are about to be freed
+    const std::size_t bytes = std::max<std::size_t>(stride * streams_, 16);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipFree(hist_[i]);
+      hist_[i] = nullptr;
+      MI_HIP(hipMalloc(&hist_[i], bytes));
+    }
+    histStride_ = stride;
+    cur_ = 0;
+  }
+  filter_ = std::move(filter);
+  fused_ = filter_->hasFused() && FusedCovers(g, channels_, inFmt_, outFmt_);
+  if (resetHistory || !sameHistory) {
+    return Reset(error);
+  }
   return true;
 }
 
@@ -463,6 +745,7 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
     return true;
   }
   const Geometry &g = filter_->geometry();
+  Reap(true);
   for (auto *&w : work_) {
     (void)hipFree(w);
     w = nullptr;
@@ -529,6 +812,13 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     return false;
   }
   hipStream_t st = static_cast<hipStream_t>(hipStream);
+  if (!OrderAfterLast(hipStream, error)) {
+    return false;
+  }
+  // the filter tables this call reads: one snapshot for the whole call (an EQ change lands between calls, i.e.
+  // between blocks), kept alive until the call's last kernel has finished
+  const std::shared_ptr<const TableSet> tabs = filter_->tables();
+  lastGeneration_ = tabs->generation;
 
   IoDesc io{};
   io.in = dIn;
@@ -549,10 +839,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
   }
   if (fused_) {
-    // one workgroup per (stream, block, channel group); launches are chunked by whole
-    // (stream, block) pairs so that the fp32 staging planes (channels * B floats per
-    // pair) stay bounded. (Measured: keeping a chunk inside the 256 MiB Infinity Cache
-    // gains less than launching fewer, fuller rounds of workgroups -- profiles/r01_summary.md.)
+    // one workgroup per (stream, block, channel group); launches are chunked by whole (stream, block) pairs so that
+    // the fp32 staging planes (channels * B floats per pair) stay bounded.
     PickChannelGroup(blocks);
     const bool split = filter_->fusedSplit();
     const bool ext = cg_ < channels_ || split;  // the split kernel has no epilogue of its own
@@ -568,12 +856,38 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       const std::size_t wgs = chunk * groups_ - (chunk * groups_) % wgCapacity_;
       chunk = std::max<std::size_t>(1, wgs / groups_);
     }
-    if (chunk * perPair > scratchBytes_) {
+    // Pipelined launches (planes leave the kernel, ext): the call is cut into chunks of a few full-chip rounds of
+    // workgroups; the interleave kernel of chunk k runs on the engine's second stream while the transform kernel of
+    // chunk k+1 runs on the caller's -- the bandwidth-bound pass fills the issue slots and the tail of the
+    // compute-bound one instead of following it. Two plane buffers alternate.
+    // Only where several workgroups share a CU (K <= 4096): a K = 16384 workgroup owns its CU's whole LDS and
+    // register file, so an interleave workgroup that lands there keeps a transform workgroup out (measured: configs 4
+    // and 5 lose 17-22 % with pipelined launches, config 3 gains 4 %; profiles/r02_b_pipelined_launches.txt).
+    bool pipelined = false;
+    const bool sharedCus = wgCapacity_ >= 4 * static_cast<std::size_t>(cuCount_);
+    const char *forcePipe = std::getenv("MIUPS_EXP_PIPELINE");  // experiment switch (profiles/): 0 = never, 1 = always
+    if (ext && (forcePipe ? forcePipe[0] == '1' : sharedCus)) {
+      const std::size_t totalWgs = pairs * groups_;
+      const std::size_t rounds = (totalWgs + wgCapacity_ - 1) / wgCapacity_;
+      std::size_t chunkRounds = std::max<std::size_t>(1, rounds / 8);
+      if (const char *cr = std::getenv("MIUPS_EXP_CHUNK_ROUNDS")) {  // experiment switch (profiles/)
+        chunkRounds = static_cast<std::size_t>(std::max(1, std::atoi(cr)));
+      }
+      std::size_t c = std::max<std::size_t>(1, chunkRounds * wgCapacity_ / groups_);
+      c = std::min(c, std::max<std::size_t>(1, (budget / 2) / perPair));
+      if (c < pairs) {
+        chunk = c;
+        pipelined = true;
+      }
+    }
+    const std::size_t planeBytes = chunk * perPair * (pipelined ? 2 : 1);
+    if (planeBytes > scratchBytes_) {
+      Reap(true);
       (void)hipFree(scratch_);
       scratch_ = nullptr;
       scratchBytes_ = 0;
-      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), chunk * perPair));
-      scratchBytes_ = chunk * perPair;
+      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), planeBytes));
+      scratchBytes_ = planeBytes;
     }
     io.scratch = scratch_;
     io.cg = cg_;
@@ -590,6 +904,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       const long long planeFloats = (total + 3) / 4 * 4;
       const std::size_t need = static_cast<std::size_t>(planeFloats) * channels_ * streams_ * sizeof(float);
       if (need > planarBytes_) {
+        Reap(true);
         (void)hipFree(planar_);
         planar_ = nullptr;
         planarBytes_ = 0;
@@ -613,14 +928,30 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     ioF.split_planes = split ? 1 : 0;
     const bool quad = ioF.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 &&
                       g.Bc % 4 == 0;
-    for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {
+    hipStream_t aux = static_cast<hipStream_t>(aux_);
+    std::size_t k = 0;
+    bool usedHalf[2] = {false, false};
+    for (std::size_t p0 = 0; p0 < pairs; p0 += chunk, ++k) {
       const std::size_t np = std::min<std::size_t>(chunk, pairs - p0);
+      const int half = pipelined ? static_cast<int>(k & 1) : 0;
+      float *planes = scratch_ + static_cast<std::size_t>(half) * chunk * (perPair / sizeof(float));
+      hipEvent_t evFused = static_cast<hipEvent_t>(pipeEv_[half]), evFrames = static_cast<hipEvent_t>(pipeEv_[2 + half]);
+      if (pipelined && usedHalf[half]) {
+        MI_HIP(hipStreamWaitEvent(st, evFrames, 0));  // the frames of chunk k-2 are out of this plane buffer
+      }
       ioF.item0 = static_cast<int>(p0 * groups_);
-      if (!DispatchFused(g, ioF, *filter_, static_cast<unsigned>(np * groups_), st, error)) {
+      ioF.scratch = planes;
+      if (!DispatchFused(g, ioF, tabs->fused(), split, static_cast<unsigned>(np * groups_), st, error)) {
         return false;
       }
       if (!ext) {
         continue;
+      }
+      hipStream_t ist = st;
+      if (pipelined) {
+        MI_HIP(hipEventRecord(evFused, st));
+        MI_HIP(hipStreamWaitEvent(aux, evFused, 0));
+        ist = aux;
       }
       // staging planes of this chunk -> interleaved PCM frames
       if (quad) {
@@ -629,19 +960,30 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
         const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
         if (outFmt_ == kF32) {
-          hipLaunchKernelGGL(interleave_quad_kernel<kF32>, grid, dim3(threads), 0, st, g, ioF, scratch_,
+          hipLaunchKernelGGL(interleave_quad_kernel<kF32>, grid, dim3(threads), 0, ist, g, ioF, planes,
                              static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
         } else {
-          hipLaunchKernelGGL(interleave_quad_kernel<kS32>, grid, dim3(threads), 0, st, g, ioF, scratch_,
+          hipLaunchKernelGGL(interleave_quad_kernel<kS32>, grid, dim3(threads), 0, ist, g, ioF, planes,
                              static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
         }
       } else {
         const long long total = static_cast<long long>(np) * g.B * channels_;
-        hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, st, g, ioF, scratch_,
+        hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, ist, g, ioF, planes,
                            static_cast<int>(p0), static_cast<int>(np));
       }
       if (!HipOk(hipGetLastError(), "interleave kernel", error)) {
         return false;
+      }
+      if (pipelined) {
+        MI_HIP(hipEventRecord(evFrames, aux));
+        usedHalf[half] = true;
+      }
+    }
+    if (pipelined) {  // join: the caller's stream continues after the last frames are written
+      for (int half = 0; half < 2; ++half) {
+        if (usedHalf[half]) {
+          MI_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(pipeEv_[2 + half]), 0));
+        }
       }
     }
   } else {
@@ -657,10 +999,10 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       const long long elems = static_cast<long long>(n) * g.K;
       hipLaunchKernelGGL(gen_load_kernel, dim3(Blocks(elems, threads)), dim3(threads), 0, st, g, io, work_[0],
                          static_cast<int>(item0), n);
-      cf *Z = StagedFft<-1>(work_[0], work_[1], filter_->tw(), g.log2k, n, st);
+      cf *Z = StagedFft<-1>(work_[0], work_[1], tabs->tw, g.log2k, n, st);
       hipLaunchKernelGGL(gen_multiply_kernel, dim3(Blocks(elems, threads)), dim3(threads), 0, st, g, Z, work_[2],
-                         filter_->Gs(), filter_->Gc(), filter_->Wm(), n);
-      cf *y = StagedFft<+1>(work_[2], work_[3], filter_->tw(), g.log2k, static_cast<long long>(n) * g.P, st);
+                         tabs->Gs, tabs->Gc, tabs->Wm, n);
+      cf *y = StagedFft<+1>(work_[2], work_[3], tabs->tw, g.log2k, static_cast<long long>(n) * g.P, st);
       hipLaunchKernelGGL(gen_store_kernel, dim3(Blocks(elems * g.P, threads)), dim3(threads), 0, st, g, io, y,
                          static_cast<int>(item0), n);
     }
@@ -683,9 +1025,13 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     }
     cur_ = 1 - cur_;
   }
-  return true;
+  return MarkDone(hipStream, tabs, error);
 }
 
+// Host buffers. The call is cut into consecutive sub-batches of blocks; sub-batch j's H2D copy, its kernels and its D2H
+// copy run on three streams, each gated by events, through two device slots per direction: while the kernels of j run,
+// j+1 is being copied in and j-1 copied out. (A block depends on earlier blocks only through the input history, which
+// ProcessDevice carries from one sub-batch to the next on the compute stream.) Synchronous for the caller.
 bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std::size_t outStride,
                          std::size_t blocks, std::string *error) {
   if (!hIn || !hOut || blocks == 0) {
@@ -698,49 +1044,101 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     return false;
   }
   const Geometry &g = filter_->geometry();
-  const std::size_t inRow = blocks * g.n_in * channels_ * pcm_bytes(inFmt_);
-  const std::size_t outRow = blocks * static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
-  if (streams_ > 1 && (inStride < inRow || outStride < outRow)) {
+  const std::size_t inBlock = static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
+  const std::size_t outBlock = static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
+  if (streams_ > 1 && (inStride < blocks * inBlock || outStride < blocks * outBlock)) {
     if (error) {
       *error = "stream stride smaller than one stream's data";
     }
     return false;
   }
-  const std::size_t inBytes = inRow * streams_, outBytes = outRow * streams_;
-  if (inBytes > stageInBytes_) {
-    (void)hipFree(stageIn_);
-    stageIn_ = nullptr;
-    stageInBytes_ = 0;
-    MI_HIP(hipMalloc(&stageIn_, inBytes));
-    stageInBytes_ = inBytes;
+  // sub-batch size: up to 8 per call, but never so small that a launch cannot fill the chip
+  std::size_t nsub = std::min<std::size_t>(8, blocks);
+  if (const char *v = std::getenv("MIUPS_EXP_HOST_SUBBATCHES")) {  // experiment switch (profiles/)
+    nsub = std::min<std::size_t>(blocks, static_cast<std::size_t>(std::max(1, std::atoi(v))));
   }
-  if (outBytes > stageOutBytes_) {
-    (void)hipFree(stageOut_);
-    stageOut_ = nullptr;
-    stageOutBytes_ = 0;
-    MI_HIP(hipMalloc(&stageOut_, outBytes));
-    stageOutBytes_ = outBytes;
+  const std::size_t minBlocks = std::max<std::size_t>(1, (static_cast<std::size_t>(cuCount_) + streams_ * channels_ - 1) /
+                                                             (static_cast<std::size_t>(streams_) * channels_));
+  std::size_t sb = std::max((blocks + nsub - 1) / nsub, std::min(blocks, minBlocks));
+  nsub = (blocks + sb - 1) / sb;
+  const std::size_t inRow = sb * inBlock, outRow = sb * outBlock;  // device-side stream strides
+  if (inRow * streams_ > stageInBytes_ || outRow * streams_ > stageOutBytes_) {
+    Reap(true);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipFree(stageIn_[i]);
+      (void)hipFree(stageOut_[i]);
+      stageIn_[i] = stageOut_[i] = nullptr;
+    }
+    stageInBytes_ = stageOutBytes_ = 0;
+    for (int i = 0; i < 2; ++i) {
+      MI_HIP(hipMalloc(&stageIn_[i], inRow * streams_));
+      MI_HIP(hipMalloc(&stageOut_[i], outRow * streams_));
+    }
+    stageInBytes_ = inRow * streams_;
+    stageOutBytes_ = outRow * streams_;
   }
-  for (int s = 0; s < streams_; ++s) {
-    MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_) + s * inRow, static_cast<const char *>(hIn) + s * inStride,
-                          inRow, hipMemcpyHostToDevice, nullptr));
-  }
-  if (!ProcessDevice(stageIn_, inRow, stageOut_, outRow, blocks, nullptr, error)) {
+  hipStream_t own = static_cast<hipStream_t>(own_), h2d = static_cast<hipStream_t>(h2d_), d2h = static_cast<hipStream_t>(d2h_);
+  if (!OrderAfterLast(own_, error)) {
     return false;
   }
-  for (int s = 0; s < streams_; ++s) {
-    MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride, static_cast<const char *>(stageOut_) + s * outRow,
-                          outRow, hipMemcpyDeviceToHost, nullptr));
+  // pipeEv_[4 + slot]: input of the slot copied in; [6 + slot]: kernels of the slot done; [8 + slot]: output copied out
+  for (std::size_t j = 0; j < nsub; ++j) {
+    const int slot = static_cast<int>(j & 1);
+    const std::size_t b0 = j * sb, nb = std::min(sb, blocks - b0);
+    hipEvent_t evIn = static_cast<hipEvent_t>(pipeEv_[4 + slot]), evRun = static_cast<hipEvent_t>(pipeEv_[6 + slot]),
+               evOut = static_cast<hipEvent_t>(pipeEv_[8 + slot]);
+    if (j >= 2) {
+      MI_HIP(hipStreamWaitEvent(h2d, evRun, 0));  // the kernels of j-2 have read this input slot
+    }
+    for (int s = 0; s < streams_; ++s) {
+      MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow,
+                            static_cast<const char *>(hIn) + s * inStride + b0 * inBlock, nb * inBlock,
+                            hipMemcpyHostToDevice, h2d));
+    }
+    MI_HIP(hipEventRecord(evIn, h2d));
+    MI_HIP(hipStreamWaitEvent(own, evIn, 0));
+    if (j >= 2) {
+      MI_HIP(hipStreamWaitEvent(own, evOut, 0));  // the output of j-2 has left this output slot
+    }
+    if (!ProcessDevice(stageIn_[slot], inRow, stageOut_[slot], outRow, nb, own_, error)) {
+      (void)hipStreamSynchronize(h2d);
+      (void)hipStreamSynchronize(own);
+      (void)hipStreamSynchronize(d2h);
+      return false;
+    }
+    MI_HIP(hipEventRecord(evRun, own));
+    MI_HIP(hipStreamWaitEvent(d2h, evRun, 0));
+    for (int s = 0; s < streams_; ++s) {
+      MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlock,
+                            static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock,
+                            hipMemcpyDeviceToHost, d2h));
+    }
+    MI_HIP(hipEventRecord(evOut, d2h));
   }
-  MI_HIP(hipStreamSynchronize(nullptr));
+  MI_HIP(hipStreamSynchronize(d2h));
+  MI_HIP(hipStreamSynchronize(own));
   return true;
+}
+
+void *HostAlloc(std::size_t bytes, std::string *error) {
+  void *p = nullptr;
+  if (!HipOk(hipHostMalloc(&p, std::max<std::size_t>(bytes, 1), hipHostMallocDefault), "hipHostMalloc", error)) {
+    return nullptr;
+  }
+  return p;
+}
+
+void HostFree(void *p) {
+  if (p) {
+    (void)hipHostFree(p);
+  }
 }
 
 bool Engine::EnableTiming(int slots, std::string *error) {
   if (!UseDevice(filter_->device(), error)) {
     return false;
   }
-  MI_HIP(hipDeviceSynchronize());
+  Reap(true);  // no recorded pair is still pending when the ring is replaced
   for (void *e : evStart_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
