@@ -176,6 +176,47 @@ int mi_engine_enable_kernel_timing(mi_engine *e, int slots);
 double mi_engine_last_kernel_ms(mi_engine *e);
 int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double *max_ms, int *count);
 
+/* ----------------------------------------------------------------- (2b) --
+ * Multi-GPU: independent streams sharded over the GPUs of one node. Stream s runs on slot s mod n_devices; every
+ * slot owns a device, its own filter tables, histories, HIP streams, pinned staging and one host worker thread. No
+ * data is exchanged between devices (reference: channels are independent objects, alsa_streamer_main.cpp:248-250,
+ * 537-553). A device may be listed twice (two slots on one GPU). Creation fails with a message when a
+ * listed device is not visible.
+ */
+typedef struct mi_multi mi_multi;
+int mi_multi_create(const char *json_path, int flags, const int *devices, size_t n_devices, int streams, int channels,
+                    int in_fmt, int out_fmt, mi_multi **out, char *err, size_t errcap);
+void mi_multi_destroy(mi_multi *m);
+int mi_multi_set_eq(mi_multi *m, const char *apo_text, double fs_out);
+int mi_multi_reset(mi_multi *m);
+/* all streams, HOST buffers, stream s at base + s*stride; returns when every device has finished */
+int mi_multi_process_host(mi_multi *m, const void *h_in, size_t in_stream_stride_bytes, void *h_out,
+                          size_t out_stream_stride_bytes, size_t blocks);
+size_t mi_multi_in_frames_per_block(const mi_multi *m);
+size_t mi_multi_out_frames_per_block(const mi_multi *m);
+int mi_multi_device_of_stream(const mi_multi *m, int stream);
+/* the partition itself (pure): slot_of_stream[s] = s mod slots */
+int mi_multi_partition(int streams, int slots, int *slot_of_stream);
+
+/* ----------------------------------------------------------------- (2c) --
+ * Resident spectra for every (rate family, ratio, phase) a filter directory serves: a change of input rate inside a
+ * family, of the ratio or of the phase setting is mi_engine_rebind to a filter that is already in HBM (reference
+ * keys: src/alsa/alsa_filter_selector.cpp:33-55; "same-family switching is instant",
+ * src/audio/auto_negotiation.cpp:139-152).
+ */
+typedef struct mi_bank mi_bank;
+int mi_bank_load(int device, const char *filter_dir, mi_bank **out, char *warnings, size_t warncap, char *err,
+                 size_t errcap);
+void mi_bank_release(mi_bank *b);
+size_t mi_bank_size(const mi_bank *b);
+/* entry i: family base rate (44100 | 48000), ratio, phase ("min" | "linear"), sidecar path, geometry */
+int mi_bank_entry(const mi_bank *b, size_t i, unsigned *family_base_rate, unsigned *ratio, char *phase, size_t phasecap,
+                  char *path, size_t pathcap, mi_ups_config *config);
+/* a new handle on the resident filter for this key (release it with mi_filter_release; the tables stay in the
+ * bank), or NULL with the selector's message */
+mi_filter *mi_bank_select(const mi_bank *b, unsigned input_rate, unsigned ratio, const char *phase, char *err,
+                          size_t errcap);
+
 /* ------------------------------------------------------------------ (3) --
  * Host-only helpers (no GPU needed): the caller-side logic around the path,
  * exported so the streamer and the CPU test-suite use one implementation.
@@ -204,6 +245,70 @@ int mi_eq_biquad(int enabled, int type, double freq, double gain, double q, doub
 /* computeEqResponseForFft / computeEqMagnitudeForFft, host fp64 */
 int mi_eq_response_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_reim);
 int mi_eq_magnitude_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_mag);
+
+/* Rate-family detection and output-rate negotiation (src/audio/auto_negotiation.cpp:13-155). The DAC is given as the
+ * reference's capability probe reports it: valid flag, min/max rate, optional list of discrete rates. */
+typedef struct mi_negotiated {
+  int input_rate;
+  int family;      /* 0 unknown, 1 = 44.1k family, 2 = 48k family */
+  int output_rate;
+  int ratio;
+  int valid;
+  int requires_reconfiguration;
+  char error[256];
+} mi_negotiated;
+int mi_rate_family(int sample_rate);
+int mi_same_family(int rate_a, int rate_b);
+int mi_upsample_ratio(int input_rate, int output_rate);
+int mi_negotiate(int input_rate, int dac_valid, int dac_min_rate, int dac_max_rate, const int *dac_rates, size_t n_rates,
+                 int current_output_rate, mi_negotiated *out);
+
+/* config.json of the reference's control plane (release/config.example.json): the keys the data plane acts on. */
+typedef struct mi_runtime_config {
+  int eq_enabled;
+  char eq_profile[256];
+  char eq_profile_path[1024];
+  unsigned ratio;
+  char phase_type[32];
+  char filter_directory[1024];
+  unsigned sample_rate, channels, period_frames, buffer_frames;
+  char format[32];
+  char input_device[128], output_device[128];
+} mi_runtime_config;
+int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char *err, size_t errcap);
+
+/* SPSC PCM ring (contract of include/io/audio_ring_buffer.h:23-100, on bytes) -- exported for the tests */
+typedef struct mi_ring mi_ring;
+mi_ring *mi_ring_create(size_t capacity_bytes);
+void mi_ring_destroy(mi_ring *r);
+int mi_ring_write(mi_ring *r, const void *data, size_t bytes);  /* 1 = written, 0 = would not fit (nothing written) */
+int mi_ring_read(mi_ring *r, void *dst, size_t bytes);           /* 1 = read, 0 = not that much available */
+size_t mi_ring_available_to_read(const mi_ring *r);
+size_t mi_ring_available_to_write(const mi_ring *r);
+void mi_ring_clear(mi_ring *r);
+
+/* The streaming loop of the reference (alsa_streamer_main.cpp:428-611) over callbacks: read one period, stage it,
+ * process every complete block that fits, drain period*ratio chunks, write silence when nothing is ready, drop the
+ * staging on overflow. process == NULL or block_in_frames == 0: PCM pass-through. `running` is polled; set it to 0
+ * from a signal handler to stop. between_blocks (may be NULL) runs before every process call. */
+typedef long (*mi_read_fn)(void *user, void *dst, size_t frames);
+typedef int (*mi_write_fn)(void *user, const void *src, size_t frames);
+typedef int (*mi_process_fn)(void *user, const void *in, void *out, size_t blocks);
+typedef void (*mi_between_fn)(void *user);
+typedef void (*mi_log_fn)(void *user, const char *message);
+typedef struct mi_loop_params {
+  unsigned channels;
+  int format;
+  size_t period_frames, block_in_frames, block_out_frames, max_blocks_per_call;
+  int drain_at_end; /* additive: process the zero-padded tail and flush (the reference stops at the first short read) */
+} mi_loop_params;
+typedef struct mi_loop_stats {
+  size_t periods_read, blocks_processed, frames_written, silence_frames_written, input_overflows, output_overflows,
+      process_calls;
+} mi_loop_stats;
+int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn write, mi_process_fn process,
+                       mi_between_fn between, mi_log_fn log, void *user, const volatile int *running,
+                       mi_loop_stats *stats);
 
 /* Layout facts of the fused kernel (K = 2^log2k complex points per channel-block,
  * 5 <= log2k <= 14), exported so that the CPU tests can verify bank-conflict

@@ -1,0 +1,298 @@
+"""GPU tests of the rows of SURVEY 8(f) and 8(e) that sit around the hot path: multi-GPU sharding of independent
+streams (on one GPU: one slot, and two slots on the same device, against the plain engine, bit for bit), glitch-free EQ
+activation between blocks, resident filters and switching between them, the streaming loop of the CLI."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import signal
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, real_input, rel_err
+from test_stream_host import reference_loop_model
+
+pytestmark = pytest.mark.gpu
+BIN = ROOT / "totton-rasp-gpu-dsp_amd" / "bin" / "alsa_streamer"
+PROFILES = json.loads((GOLDEN / "g4_eq_profiles.json").read_text())
+F4X = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+
+
+def synth(streams, frames, channels, seed=0):
+    x = np.clip(np.random.default_rng(seed).standard_normal((streams, frames, channels)) * 0.1, -1, 1)
+    return np.round(x * 2**31).clip(-2**31, 2**31 - 1).astype("<i4")
+
+
+# ---- multi-GPU host ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("devices,streams", [([0], 3), ([0, 0], 5), ([0, 0, 0], 2)])
+def test_multi_engine_is_bit_identical_to_one_engine(ups, gpu, devices, streams):
+    """Static partition stream s -> slot s mod G, one worker thread / filter / engine per slot: the shards never talk
+    to each other, so any slot count gives the bytes of a single engine over all streams. (Two or three slots on the
+    one GPU of the test box exercise the strided views, the worker threads and the empty-slot case.)"""
+    channels, blocks, calls = 2, 3, 2
+    filt = ups.Filter(F4X, device=gpu)
+    one = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
+    multi = ups.MultiEngine(F4X, devices, streams, channels)
+    assert multi.in_frames == one.in_frames and [multi.device_of_stream(s) for s in range(streams)] == [0] * streams
+    for k in range(calls):   # the second call runs on carried history in every slot
+        x = synth(streams, blocks * one.in_frames, channels, seed=10 + k)
+        np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+    multi.reset()
+    one.reset()
+    x = synth(streams, blocks * one.in_frames, channels, seed=99)
+    np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+    # EQ goes to every slot's filter
+    multi.set_eq(PROFILES["opra10"], 705600.0)
+    filt.set_eq(PROFILES["opra10"], 705600.0)
+    multi.reset()
+    one.reset()
+    np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+
+
+def test_multi_engine_refuses_devices_that_are_not_there(ups, gpu):
+    n = ups.device_count()
+    with pytest.raises(ups.UpsamplerError, match=f"device {n} requested but only {n} HIP device"):
+        ups.MultiEngine(F4X, [0, n], 4, 2)
+
+
+# ---- EQ activation: swap between blocks ------------------------------------------------------------------------
+def test_eq_swap_between_blocks_is_glitch_free(ups, O, gpu):
+    """Stream block by block; activate the EQ after block 2, deactivate it after block 4. Blocks before/after a swap
+    equal the plain / EQ streams computed separately -- the carried state is input history, so a block's output
+    depends on the filter of ITS call only -- and every swap publishes a new table generation."""
+    h, taps, fft, block, L = O.read_filter(F4X)
+    filt = ups.Filter(F4X, device=gpu)
+    eng = ups.Engine(filt, 1, 2, ups.PCM_F32, ups.PCM_F32)
+    nin, nb = eng.in_frames, 6
+    x = real_input(5, nb * nin * 2).reshape(nb * nin, 2)
+    plain = eng.process_host(x, nb).view(np.float32).reshape(nb, block, 2).copy()
+    filt.set_eq(PROFILES["opra10"], 705600.0)
+    eng.reset()
+    eqd = eng.process_host(x, nb).view(np.float32).reshape(nb, block, 2).copy()
+    assert rel_err(eqd, plain) > 1e-2
+    filt.set_eq("", 705600.0)
+    eng.reset()
+    g0 = filt.generation
+    got = []
+    for b in range(nb):
+        if b == 2:
+            filt.set_eq(PROFILES["opra10"], 705600.0)
+        if b == 4:
+            filt.set_eq("", 705600.0)
+        got.append(eng.process_host(x[b * nin:(b + 1) * nin], 1).view(np.float32).reshape(block, 2).copy())
+        assert eng.last_generation == filt.generation
+    assert filt.generation == g0 + 2
+    for b in range(nb):
+        np.testing.assert_array_equal(got[b], eqd[b] if 2 <= b < 4 else plain[b])
+
+
+def test_failed_eq_rebuild_keeps_the_old_tables(ups, gpu):
+    filt = ups.Filter(F4X, device=gpu)
+    eng = ups.Engine(filt, 1, 2, ups.PCM_F32, ups.PCM_F32)
+    x = real_input(6, 2 * eng.in_frames * 2).reshape(-1, 2)
+    before = eng.process_host(x, 2).copy()
+    g0 = filt.generation
+    ups.lib.mi_debug_fail_next_table_upload(filt._h)
+    with pytest.raises(ups.UpsamplerError, match="table upload failed"):
+        filt.set_eq(PROFILES["opra10"], 705600.0)
+    assert filt.generation == g0                     # nothing was published
+    eng.reset()
+    np.testing.assert_array_equal(eng.process_host(x, 2), before)   # and the filter still works, unchanged
+    filt.set_eq(PROFILES["opra10"], 705600.0)                       # the next attempt goes through
+    assert filt.generation == g0 + 1
+
+
+def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
+    """A thread streams 64-block calls back to back on its own HIP stream while the main thread swaps the EQ four
+    times. No call may take longer than a handful of normal calls: the swap uploads beside the live tables on a
+    private stream and never synchronises the device."""
+    from bench import Hip
+
+    hip = Hip()
+    hip.check(hip.lib.hipSetDevice(gpu), "hipSetDevice")
+    filt = ups.Filter(F4X, device=gpu)
+    eng = ups.Engine(filt, 1, 2, ups.PCM_S32, ups.PCM_S32)
+    blocks = 64
+    d_in, d_out = hip.malloc(eng.in_bytes(blocks)), hip.malloc(eng.out_bytes(blocks))
+    hip.h2d(d_in, synth(1, blocks * eng.in_frames, 2))
+    stream = hip.stream()
+    times, stop = [], threading.Event()
+
+    def run():
+        hip.lib.hipSetDevice(gpu)
+        while not stop.is_set():
+            t0 = time.perf_counter()
+            eng.process_device(d_in, d_out, blocks, stream)
+            hip.check(hip.lib.hipStreamSynchronize(C.c_void_p(stream)), "sync")
+            times.append(time.perf_counter() - t0)
+
+    t = threading.Thread(target=run)
+    t.start()
+    time.sleep(0.3)
+    n_before = len(times)
+    swaps = []
+    for k in range(4):
+        t0 = time.perf_counter()
+        filt.set_eq(PROFILES["opra10"] if k % 2 == 0 else "", 705600.0)
+        swaps.append(time.perf_counter() - t0)
+        time.sleep(0.05)
+    time.sleep(0.2)
+    stop.set()
+    t.join()
+    hip.check(hip.lib.hipFree(d_in), "hipFree")
+    hip.check(hip.lib.hipFree(d_out), "hipFree")
+    assert n_before > 20 and len(times) > n_before + 20
+    typical = float(np.median(times))
+    assert max(times[5:]) < 10 * typical + 5e-3, (max(times[5:]), typical, swaps)
+
+
+# ---- resident spectra and switching -------------------------------------------------------------------------------
+def test_filter_bank_resident_filters_and_rebind(ups, O, gpu):
+    bank = ups.FilterBank(ROOT / "data" / "coefficients", device=gpu)
+    ent = {(e["family"], e["ratio"], e["phase"]): e for e in bank.entries()}
+    # everything the shipped directory serves: 8 min-phase geometries + this repo's 8x linear one
+    for fam in (44100, 48000):
+        for ratio in (2, 4, 8, 16):
+            assert (fam, ratio, "min") in ent, (fam, ratio)
+    assert (48000, 8, "linear") in ent and ent[(48000, 8, "linear")]["config"]["taps"] == 160001
+    with pytest.raises(ups.UpsamplerError, match="Unsupported input rate family: 32000"):
+        bank.select(32000, 2, "min")
+    with pytest.raises(ups.UpsamplerError, match="Filter file not found"):
+        bank.select(44100, 1, "min")
+    # 88.2 kHz in -> 8x, then the source switches to 176.4 kHz -> 4x of the same family (same output rate): a rebind
+    f8, f4 = bank.select(88200, 8, "min"), bank.select(176400, 4, "min")
+    eng = ups.Engine(f8, 1, 2, ups.PCM_F32, ups.PCM_F32)
+    h8 = O.read_filter(ent[(44100, 8, "min")]["path"])
+    h4 = O.read_filter(ent[(44100, 4, "min")]["path"])
+    x8 = real_input(1, 2 * eng.in_frames * 2).reshape(-1, 2)
+    y8 = eng.process_host(x8, 2).view(np.float32).reshape(-1, 2)
+    assert rel_err(y8[:, 0], O.truth_stream(x8[:, 0], h8[0], 8, 2, h8[3]).reshape(-1)) <= 1e-5
+    eng.rebind(f4)   # different history length: starts from silence, like a fresh LoadFilter
+    assert eng.in_frames == h4[3] // 4
+    x4 = real_input(2, 2 * eng.in_frames * 2).reshape(-1, 2)
+    y4 = eng.process_host(x4, 2).view(np.float32).reshape(-1, 2)
+    assert rel_err(y4[:, 1], O.truth_stream(x4[:, 1], h4[0], 4, 2, h4[3]).reshape(-1)) <= 1e-5
+    # the bank's tables are shared, not copied: a second handle on the same key is the same filter generation
+    assert bank.select(176400, 4, "min").generation == f4.generation
+    # same geometry (another handle on the same key): the history carries over the rebind
+    eng.reset()
+    a = eng.process_host(x4[:eng.in_frames], 1).copy()
+    eng.rebind(bank.select(176400, 4, "min"))
+    b = eng.process_host(x4[eng.in_frames:], 1).copy()
+    np.testing.assert_array_equal(np.concatenate([a, b]), y4.view(np.uint8).reshape(-1))
+
+
+# ---- the streaming loop through the CLI ----------------------------------------------------------------------------
+def run_cli(args, timeout=300):
+    return subprocess.run([str(BIN), *map(str, args)], capture_output=True, text=True, timeout=timeout)
+
+
+def test_cli_streaming_loop_equals_file_pipeline_behind_the_reference_burst_pattern(ups, tmp_path):
+    """--loop reads the file in --period chunks through the rings. Its output is the file pipeline's output cut into
+    period*ratio chunks with the silence periods the reference's greedy drain inserts (model: test_stream_host.py)."""
+    nin = 12768
+    frames = 3 * nin + 777
+    period = 4096
+    x = synth(1, frames, 2, seed=3)[0]
+    (tmp_path / "in.raw").write_bytes(x.tobytes())
+    common = ["--in-file", tmp_path / "in.raw", "--rate", 44100, "--filter-dir", F4X.parent, "--ratio", 4, "--phase", "min",
+              "--channels", 2, "--format", "s32"]
+    r = run_cli([*common, "--out-file", tmp_path / "pipe.raw", "--blocks-per-call", 2])
+    assert r.returncode == 0, r.stderr
+    pipe = (tmp_path / "pipe.raw").read_bytes()
+    assert len(pipe) == frames * 4 * 8
+    r = run_cli([*common, "--out-file", tmp_path / "loop.raw", "--loop", "--period", period, "--drain", "--blocks-per-call", 1])
+    assert r.returncode == 0, r.stderr
+    assert f"File streaming started: input 44100 Hz, output 176400 Hz, period {period} frames" in r.stderr
+    loop = (tmp_path / "loop.raw").read_bytes()
+    # the model replays the loop with "the engine" = slices of the file pipeline's output
+    blocks_out = [pipe[i:i + nin * 4 * 8] for i in range(0, len(pipe) + nin * 4 * 8, nin * 4 * 8)]
+    it = iter(blocks_out)
+
+    def proc(blk, k):
+        out = b"".join(next(it) for _ in range(k))
+        return out + bytes(k * nin * 4 * 8 - len(out))   # the zero-padded tail block is longer than the trimmed file
+
+    want, silence = reference_loop_model(x.tobytes(), 8, period, nin, nin * 4, proc, 1, True)
+    assert loop == b"".join(want)
+    assert f"({silence} of silence)" in r.stderr and silence > 0
+    # a period larger than the block is clamped with the reference's message (alsa_streamer_main.cpp:413-417)
+    r = run_cli([*common, "--out-file", tmp_path / "loop2.raw", "--loop", "--period", 20000, "--drain"])
+    assert r.returncode == 0 and "ALSA period is larger than filter input block; clamping to 12768 frames" in r.stderr
+    assert (tmp_path / "loop2.raw").read_bytes() == pipe   # period == block: no silence, byte-identical
+
+
+def test_cli_eq_activation_by_config_and_sighup(ups, O, tmp_path):
+    """config.json as the web UI writes it (eqEnabled / eqProfilePath); the streamer applies it at start and re-reads
+    it on SIGHUP between two blocks."""
+    (tmp_path / "eq.txt").write_text(PROFILES["opra10"])
+    cfg = tmp_path / "config.json"
+    cfg.write_text(json.dumps({"eqEnabled": True, "eqProfile": "opra10", "eqProfilePath": str(tmp_path / "eq.txt")}))
+    nin = 12768
+    x = synth(1, 2 * nin, 2, seed=8)[0]
+    (tmp_path / "in.raw").write_bytes(x.tobytes())
+    common = ["--in-file", tmp_path / "in.raw", "--rate", 44100, "--filter", F4X, "--channels", 2, "--format", "s32"]
+    r = run_cli([*common, "--out-file", tmp_path / "a.raw", "--config", cfg])
+    assert r.returncode == 0 and "EQ reloaded: opra10" in r.stderr, r.stderr
+    r = run_cli([*common, "--out-file", tmp_path / "b.raw", "--eq", tmp_path / "eq.txt"])
+    assert r.returncode == 0
+    assert (tmp_path / "a.raw").read_bytes() == (tmp_path / "b.raw").read_bytes()
+    cfg.write_text(json.dumps({"eqEnabled": False, "eqProfile": None, "eqProfilePath": None}))
+    r = run_cli([*common, "--out-file", tmp_path / "c.raw", "--config", cfg])
+    assert r.returncode == 0 and "EQ disabled" in r.stderr
+    r = run_cli([*common, "--out-file", tmp_path / "d.raw"])
+    assert (tmp_path / "c.raw").read_bytes() == (tmp_path / "d.raw").read_bytes()
+    # SIGHUP while streaming from a pipe that never ends: the reload line appears, the process stops on SIGINT with 0
+    fifo = tmp_path / "in.fifo"
+    os.mkfifo(fifo)
+    p = subprocess.Popen([str(BIN), "--in-file", str(fifo), "--out-file", os.devnull, "--rate", "44100", "--filter", str(F4X),
+                          "--channels", "2", "--format", "s32", "--loop", "--period", "4096", "--config", str(cfg)],
+                         stderr=subprocess.PIPE, text=True)
+    feeder_stop = threading.Event()
+
+    def feed():
+        with open(fifo, "wb") as f:
+            chunk = x[:4096].tobytes()
+            try:
+                while not feeder_stop.is_set():
+                    f.write(chunk)
+                    time.sleep(0.002)
+            except BrokenPipeError:
+                pass
+
+    t = threading.Thread(target=feed)
+    t.start()
+    time.sleep(1.5)
+    cfg.write_text(json.dumps({"eqEnabled": True, "eqProfile": "opra10", "eqProfilePath": str(tmp_path / "eq.txt")}))
+    p.send_signal(signal.SIGHUP)
+    time.sleep(1.5)
+    p.send_signal(signal.SIGINT)
+    feeder_stop.set()
+    try:
+        _, err = p.communicate(timeout=60)
+    finally:
+        t.join()
+    assert p.returncode == 0, err
+    assert "EQ disabled" in err and "EQ reloaded: opra10" in err and "File streaming stopped" in err
+
+
+def test_cli_multi_gpu_file_mode(ups, tmp_path):
+    """--gpus 0,0 --streams 3: three equal-length streams in one file, sharded over two slots; same bytes as one device."""
+    nin = 12768
+    x = synth(3, 2 * nin + 100, 2, seed=4)
+    (tmp_path / "in.raw").write_bytes(x.tobytes())
+    common = ["--in-file", tmp_path / "in.raw", "--rate", 44100, "--filter", F4X, "--channels", 2, "--format", "s32",
+              "--streams", 3, "--blocks-per-call", 2]
+    r = run_cli([*common, "--out-file", tmp_path / "one.raw"])
+    assert r.returncode == 0, r.stderr
+    r = run_cli([*common, "--out-file", tmp_path / "two.raw", "--gpus", "0,0"])
+    assert r.returncode == 0, r.stderr
+    one = (tmp_path / "one.raw").read_bytes()
+    assert len(one) == x.nbytes * 4 and one == (tmp_path / "two.raw").read_bytes()
+    r = run_cli([*common, "--out-file", tmp_path / "x.raw", "--gpus", "0,7"])
+    assert r.returncode == 1 and "device 7 requested but only" in r.stderr

@@ -37,6 +37,37 @@ class UpsamplerError(RuntimeError):
     pass
 
 
+class _Negotiated(C.Structure):
+    _fields_ = [("input_rate", C.c_int), ("family", C.c_int), ("output_rate", C.c_int), ("ratio", C.c_int),
+                ("valid", C.c_int), ("requires_reconfiguration", C.c_int), ("error", C.c_char * 256)]
+
+
+class _RuntimeConfig(C.Structure):
+    _fields_ = [("eq_enabled", C.c_int), ("eq_profile", C.c_char * 256), ("eq_profile_path", C.c_char * 1024),
+                ("ratio", C.c_uint), ("phase_type", C.c_char * 32), ("filter_directory", C.c_char * 1024),
+                ("sample_rate", C.c_uint), ("channels", C.c_uint), ("period_frames", C.c_uint),
+                ("buffer_frames", C.c_uint), ("format", C.c_char * 32), ("input_device", C.c_char * 128),
+                ("output_device", C.c_char * 128)]
+
+
+class _LoopParams(C.Structure):
+    _fields_ = [("channels", C.c_uint), ("format", C.c_int), ("period_frames", C.c_size_t),
+                ("block_in_frames", C.c_size_t), ("block_out_frames", C.c_size_t), ("max_blocks_per_call", C.c_size_t),
+                ("drain_at_end", C.c_int)]
+
+
+class _LoopStats(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("periods_read", "blocks_processed", "frames_written", "silence_frames_written",
+                                          "input_overflows", "output_overflows", "process_calls")]
+
+
+READ_FN = C.CFUNCTYPE(C.c_long, C.c_void_p, C.c_void_p, C.c_size_t)
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+BETWEEN_FN = C.CFUNCTYPE(None, C.c_void_p)
+LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+
+
 class _Config(C.Structure):
     _fields_ = [("taps", C.c_size_t), ("fft_size", C.c_size_t), ("block_size", C.c_size_t),
                 ("upsample_factor", C.c_size_t), ("coefficients_path", C.c_char * 1024)]
@@ -85,6 +116,34 @@ def _load():
         "mi_engine_enable_kernel_timing": (i32, [vp, i32]),
         "mi_engine_last_kernel_ms": (dbl, [vp]),
         "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
+        "mi_multi_create": (i32, [cp, i32, C.POINTER(i32), sz, i32, i32, i32, i32, C.POINTER(vp), cp, sz]),
+        "mi_multi_destroy": (None, [vp]),
+        "mi_multi_set_eq": (i32, [vp, cp, dbl]),
+        "mi_multi_reset": (i32, [vp]),
+        "mi_multi_process_host": (i32, [vp, vp, sz, vp, sz, sz]),
+        "mi_multi_in_frames_per_block": (sz, [vp]),
+        "mi_multi_out_frames_per_block": (sz, [vp]),
+        "mi_multi_device_of_stream": (i32, [vp, i32]),
+        "mi_multi_partition": (i32, [i32, i32, C.POINTER(i32)]),
+        "mi_bank_load": (i32, [i32, cp, C.POINTER(vp), cp, sz, cp, sz]),
+        "mi_bank_release": (None, [vp]),
+        "mi_bank_size": (sz, [vp]),
+        "mi_bank_entry": (i32, [vp, sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint), cp, sz, cp, sz, C.POINTER(_Config)]),
+        "mi_bank_select": (vp, [vp, C.c_uint, C.c_uint, cp, cp, sz]),
+        "mi_rate_family": (i32, [i32]),
+        "mi_same_family": (i32, [i32, i32]),
+        "mi_upsample_ratio": (i32, [i32, i32]),
+        "mi_negotiate": (i32, [i32, i32, i32, i32, C.POINTER(i32), sz, i32, C.POINTER(_Negotiated)]),
+        "mi_parse_runtime_config": (i32, [cp, C.POINTER(_RuntimeConfig), cp, sz]),
+        "mi_ring_create": (vp, [sz]),
+        "mi_ring_destroy": (None, [vp]),
+        "mi_ring_write": (i32, [vp, vp, sz]),
+        "mi_ring_read": (i32, [vp, vp, sz]),
+        "mi_ring_available_to_read": (sz, [vp]),
+        "mi_ring_available_to_write": (sz, [vp]),
+        "mi_ring_clear": (None, [vp]),
+        "mi_stream_loop_run": (i32, [C.POINTER(_LoopParams), READ_FN, WRITE_FN, PROCESS_FN, BETWEEN_FN, LOG_FN, vp,
+                                     C.POINTER(i32), C.POINTER(_LoopStats)]),
         "mi_read_filter": (i32, [cp, C.POINTER(_Config), cp, sz]),
         "mi_resolve_filter_path": (i32, [cp, cp, cp, C.c_uint, C.c_uint, cp, sz, cp, sz]),
         "mi_parse_format": (i32, [cp]),
@@ -124,7 +183,13 @@ EXPORTED_SYMBOLS = [
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
     "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_engine_rebind", "mi_filter_generation",
     "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
-    "mi_engine_kernel_ms_stats", "mi_read_filter",
+    "mi_engine_kernel_ms_stats", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
+    "mi_multi_process_host", "mi_multi_in_frames_per_block", "mi_multi_out_frames_per_block",
+    "mi_multi_device_of_stream", "mi_multi_partition", "mi_bank_load", "mi_bank_release", "mi_bank_size",
+    "mi_bank_entry", "mi_bank_select", "mi_rate_family", "mi_same_family", "mi_upsample_ratio", "mi_negotiate",
+    "mi_parse_runtime_config", "mi_ring_create", "mi_ring_destroy", "mi_ring_write", "mi_ring_read",
+    "mi_ring_available_to_read", "mi_ring_available_to_write", "mi_ring_clear", "mi_stream_loop_run",
+    "mi_read_filter",
     "mi_resolve_filter_path", "mi_parse_format", "mi_bytes_per_sample", "mi_pcm_to_float", "mi_float_to_pcm",
     "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
     "mi_eq_magnitude_host", "mi_tables_build", "mi_tables_geometry", "mi_tables_size", "mi_tables_copy",
@@ -336,6 +401,102 @@ class Engine:
     __del__ = close
 
 
+class MultiEngine:
+    """Independent streams sharded over GPUs (stream s -> devices[s mod n]); one worker thread, filter copy and engine
+    per slot, no exchange between devices (mi_multi_*)."""
+
+    def __init__(self, json_path, devices, streams: int, channels: int, in_fmt: int = PCM_S32, out_fmt: int = PCM_S32,
+                 flags: int = LOAD_DEFAULT):
+        self.devices = list(devices)
+        self.streams, self.channels, self.in_fmt, self.out_fmt = streams, channels, in_fmt, out_fmt
+        h = C.c_void_p()
+        err = C.create_string_buffer(1280)
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        rc = lib.mi_multi_create(os.fsencode(str(json_path)), flags, dev, len(self.devices), streams, channels, in_fmt,
+                                 out_fmt, C.byref(h), err, len(err))
+        if rc != MI_OK:
+            raise UpsamplerError(err.value.decode(errors="replace") or last_error())
+        self._h = h
+        self.in_frames = int(lib.mi_multi_in_frames_per_block(h))
+        self.out_frames = int(lib.mi_multi_out_frames_per_block(h))
+
+    def in_bytes(self, blocks: int) -> int:
+        return blocks * self.in_frames * self.channels * PCM_BYTES[self.in_fmt]
+
+    def out_bytes(self, blocks: int) -> int:
+        return blocks * self.out_frames * self.channels * PCM_BYTES[self.out_fmt]
+
+    def device_of_stream(self, s: int) -> int:
+        return int(lib.mi_multi_device_of_stream(self._h, s))
+
+    def set_eq(self, apo_text: str, fs_out: float) -> None:
+        if lib.mi_multi_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def reset(self) -> None:
+        if lib.mi_multi_reset(self._h) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def process_host(self, x: np.ndarray, blocks: int, out: np.ndarray | None = None) -> np.ndarray:
+        raw = np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+        if raw.size != self.in_bytes(blocks) * self.streams:
+            raise UpsamplerError(f"input holds {raw.size} bytes, expected {self.in_bytes(blocks) * self.streams}")
+        if out is None:
+            out = np.empty(self.out_bytes(blocks) * self.streams, dtype=np.uint8)
+        rc = lib.mi_multi_process_host(self._h, raw.ctypes.data_as(C.c_void_p), self.in_bytes(blocks),
+                                       out.ctypes.data_as(C.c_void_p), self.out_bytes(blocks), blocks)
+        if rc != MI_OK:
+            raise UpsamplerError(last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class FilterBank:
+    """Every (rate family, ratio, phase) a filter directory serves, resident on one device (mi_bank_*)."""
+
+    def __init__(self, filter_dir, device: int = 0):
+        h = C.c_void_p()
+        warn, err = C.create_string_buffer(4096), C.create_string_buffer(1280)
+        if lib.mi_bank_load(device, os.fsencode(str(filter_dir)), C.byref(h), warn, len(warn), err, len(err)) != MI_OK:
+            raise UpsamplerError(err.value.decode(errors="replace") or last_error())
+        self._h = h
+        self.device = device
+        self.warnings = warn.value.decode(errors="replace")
+
+    def entries(self) -> list[dict]:
+        out = []
+        for i in range(int(lib.mi_bank_size(self._h))):
+            base, ratio = C.c_uint(), C.c_uint()
+            phase, path, cfg = C.create_string_buffer(32), C.create_string_buffer(2048), _Config()
+            lib.mi_bank_entry(self._h, i, C.byref(base), C.byref(ratio), phase, len(phase), path, len(path), C.byref(cfg))
+            out.append(dict(family=base.value, ratio=ratio.value, phase=phase.value.decode(), path=os.fsdecode(path.value),
+                            config=_cfg(cfg)))
+        return out
+
+    def select(self, input_rate: int, ratio: int, phase: str = "min") -> "Filter":
+        err = C.create_string_buffer(1280)
+        h = lib.mi_bank_select(self._h, input_rate, ratio, phase.encode(), err, len(err))
+        if not h:
+            raise UpsamplerError(err.value.decode(errors="replace"))
+        f = Filter.__new__(Filter)
+        f.device = self.device
+        f._h = C.c_void_p(h)
+        return f
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mi_bank_release(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class PinnedBuffer:
     """Page-locked host memory (mi_host_alloc) exposed as a numpy uint8 array: what mi_engine_process_host moves by
     DMA without a staging copy."""
@@ -371,6 +532,82 @@ def resolve_filter_path(filter_path: str, filter_dir: str, phase: str, ratio: in
     ok = lib.mi_resolve_filter_path(os.fsencode(filter_path), os.fsencode(filter_dir), phase.encode(), ratio,
                                     input_rate, out, len(out), err, len(err))
     return (os.fsdecode(out.value) if ok else None), err.value.decode(errors="replace")
+
+
+def rate_family(rate: int) -> int:
+    """0 unknown, 1 = 44.1k family, 2 = 48k family (auto_negotiation.cpp:13-31)."""
+    return int(lib.mi_rate_family(rate))
+
+
+def same_family(a: int, b: int) -> bool:
+    return bool(lib.mi_same_family(a, b))
+
+
+def upsample_ratio(input_rate: int, output_rate: int) -> int:
+    return int(lib.mi_upsample_ratio(input_rate, output_rate))
+
+
+def negotiate(input_rate: int, dac: dict | None, current_output_rate: int = 0) -> dict:
+    """dac: dict(min=..., max=..., rates=[...]) as the reference's capability probe reports it, or None = invalid."""
+    n = _Negotiated()
+    rates = list((dac or {}).get("rates", []))
+    arr = (C.c_int * max(len(rates), 1))(*rates)
+    lib.mi_negotiate(input_rate, 1 if dac else 0, (dac or {}).get("min", 0), (dac or {}).get("max", 0), arr, len(rates),
+                     current_output_rate, C.byref(n))
+    return dict(input_rate=n.input_rate, family=n.family, output_rate=n.output_rate, ratio=n.ratio, valid=bool(n.valid),
+                requires_reconfiguration=bool(n.requires_reconfiguration), error=n.error.decode(errors="replace"))
+
+
+def parse_runtime_config(text: str) -> tuple[bool, str, dict | None]:
+    c = _RuntimeConfig()
+    err = C.create_string_buffer(512)
+    rc = lib.mi_parse_runtime_config(text.encode(), C.byref(c), err, len(err))
+    if rc != MI_OK:
+        return False, err.value.decode(errors="replace"), None
+    d = {n: getattr(c, n) for n, _ in _RuntimeConfig._fields_}
+    d = {k: (v.decode(errors="replace") if isinstance(v, bytes) else v) for k, v in d.items()}
+    d["eq_enabled"] = bool(d["eq_enabled"])
+    return True, "", d
+
+
+def multi_partition(streams: int, slots: int) -> list[int]:
+    out = (C.c_int * max(streams, 1))()
+    if lib.mi_multi_partition(streams, slots, out) != MI_OK:
+        raise UpsamplerError("mi_multi_partition")
+    return list(out[:streams])
+
+
+def stream_loop_run(params: dict, read, write, process=None, between=None, log=None, running=None) -> tuple[bool, dict]:
+    """The streamer's loop over Python callbacks (tests): read(nframes) -> bytes, write(bytes) -> bool,
+    process(in_bytes, blocks) -> out_bytes."""
+    fb = PCM_BYTES[params["format"]] * params["channels"]
+    lp = _LoopParams(params["channels"], params["format"], params["period_frames"], params.get("block_in_frames", 0),
+                     params.get("block_out_frames", 0), params.get("max_blocks_per_call", 1),
+                     int(params.get("drain_at_end", False)))
+
+    def _read(_u, dst, frames):
+        data = read(frames)
+        C.memmove(dst, data, len(data))
+        return len(data) // fb
+
+    def _write(_u, src, frames):
+        return 1 if write(C.string_at(src, frames * fb)) else 0
+
+    def _process(_u, src, dst, blocks):
+        out = process(C.string_at(src, blocks * params["block_in_frames"] * fb), blocks)
+        if out is None or len(out) != blocks * params["block_out_frames"] * fb:
+            return 0
+        C.memmove(dst, out, len(out))
+        return 1
+
+    flag = running if running is not None else C.c_int(1)
+    st = _LoopStats()
+    rc = lib.mi_stream_loop_run(C.byref(lp), READ_FN(_read), WRITE_FN(_write),
+                                PROCESS_FN(_process) if process else C.cast(None, PROCESS_FN),
+                                BETWEEN_FN(lambda _u: between()) if between else C.cast(None, BETWEEN_FN),
+                                LOG_FN(lambda _u, m: log(m.decode())) if log else C.cast(None, LOG_FN), None,
+                                C.byref(flag), C.byref(st))
+    return rc == MI_OK, {n: int(getattr(st, n)) for n, _ in _LoopStats._fields_}
 
 
 def parse_format(name: str) -> int:

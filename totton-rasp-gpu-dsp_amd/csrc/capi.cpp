@@ -2,6 +2,7 @@
 // failure leaves a message in the thread-local last-error slot.
 #include "../../include/mi_upsampler.h"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -9,6 +10,8 @@
 #include <vector>
 
 #include "engine.h"
+#include "filter_bank.h"
+#include "multi_engine.h"
 
 using miups::DeviceFilter;
 using miups::Engine;
@@ -20,6 +23,14 @@ struct mi_filter {
 
 struct mi_engine {
   std::unique_ptr<Engine> engine;
+};
+
+struct mi_multi {
+  std::unique_ptr<miups::MultiEngine> multi;
+};
+
+struct mi_bank {
+  std::unique_ptr<miups::FilterBank> bank;
 };
 
 struct mi_ups {
@@ -466,5 +477,153 @@ int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double 
 }
 
 double mi_engine_last_kernel_ms(mi_engine *e) { return e ? e->engine->LastKernelMs() : -1.0; }
+
+
+// --------------------------------------------------------------- level 2b --
+int mi_multi_create(const char *json_path, int flags, const int *devices, size_t n_devices, int streams, int channels,
+                    int in_fmt, int out_fmt, mi_multi **out, char *err, size_t errcap) {
+  return Guard(
+      [&]() -> int {
+        if (!json_path || !devices || n_devices == 0 || !out) {
+          return Fail(MI_ERR_ARG, "null argument", err, errcap);
+        }
+        FilterConfig config;
+        std::vector<float> taps;
+        std::string error;
+        if (!miups::ReadFilter(json_path, &config, &taps, &error)) {
+          return Fail(MI_ERR_FILTER, error, err, errcap);
+        }
+        auto m = miups::MultiEngine::Create(std::vector<int>(devices, devices + n_devices), config, taps, flags, streams,
+                                            channels, in_fmt, out_fmt, &error);
+        if (!m) {
+          return Fail(MI_ERR_DEVICE, error, err, errcap);
+        }
+        *out = new mi_multi{std::move(m)};
+        CopyMessage("", err, errcap);
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+void mi_multi_destroy(mi_multi *m) { delete m; }
+
+int mi_multi_set_eq(mi_multi *m, const char *apo_text, double fs_out) {
+  return Guard(
+      [&]() -> int {
+        if (!m) {
+          return Fail(MI_ERR_ARG, "null handle");
+        }
+        std::string error;
+        return m->multi->SetEq(apo_text ? apo_text : "", fs_out, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_multi_reset(mi_multi *m) {
+  return Guard(
+      [&]() -> int {
+        if (!m) {
+          return Fail(MI_ERR_ARG, "null handle");
+        }
+        std::string error;
+        return m->multi->Reset(&error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+int mi_multi_process_host(mi_multi *m, const void *h_in, size_t in_stream_stride_bytes, void *h_out,
+                          size_t out_stream_stride_bytes, size_t blocks) {
+  return Guard(
+      [&]() -> int {
+        if (!m) {
+          return Fail(MI_ERR_ARG, "null handle");
+        }
+        std::string error;
+        return m->multi->ProcessHost(h_in, in_stream_stride_bytes, h_out, out_stream_stride_bytes, blocks, &error)
+                   ? MI_OK
+                   : Fail(MI_ERR_DEVICE, error);
+      },
+      MI_ERR_DEVICE);
+}
+
+size_t mi_multi_in_frames_per_block(const mi_multi *m) { return m ? static_cast<size_t>(m->multi->geometry().n_in) : 0; }
+size_t mi_multi_out_frames_per_block(const mi_multi *m) { return m ? static_cast<size_t>(m->multi->geometry().B) : 0; }
+int mi_multi_device_of_stream(const mi_multi *m, int stream) {
+  return (m && stream >= 0 && stream < m->multi->streams()) ? m->multi->deviceOfStream(stream) : -1;
+}
+
+int mi_multi_partition(int streams, int slots, int *slot_of_stream) {
+  if (streams < 0 || slots <= 0 || !slot_of_stream) {
+    return MI_ERR_ARG;
+  }
+  const std::vector<int> p = miups::PartitionStreams(streams, slots);
+  std::copy(p.begin(), p.end(), slot_of_stream);
+  return MI_OK;
+}
+
+// --------------------------------------------------------------- level 2c --
+int mi_bank_load(int device, const char *filter_dir, mi_bank **out, char *warnings, size_t warncap, char *err,
+                 size_t errcap) {
+  return Guard(
+      [&]() -> int {
+        if (!filter_dir || !out) {
+          return Fail(MI_ERR_ARG, "null argument", err, errcap);
+        }
+        std::string warn, error;
+        auto b = miups::FilterBank::Load(device, filter_dir, &warn, &error);
+        CopyMessage(warn, warnings, warncap);
+        if (!b) {
+          return Fail(MI_ERR_FILTER, error, err, errcap);
+        }
+        *out = new mi_bank{std::move(b)};
+        CopyMessage("", err, errcap);
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+void mi_bank_release(mi_bank *b) { delete b; }
+
+size_t mi_bank_size(const mi_bank *b) { return b ? b->bank->entries().size() : 0; }
+
+int mi_bank_entry(const mi_bank *b, size_t i, unsigned *family_base_rate, unsigned *ratio, char *phase, size_t phasecap,
+                  char *path, size_t pathcap, mi_ups_config *config) {
+  if (!b || i >= b->bank->entries().size()) {
+    return Fail(MI_ERR_ARG, "bank entry out of range");
+  }
+  const auto &e = b->bank->entries()[i];
+  if (family_base_rate) {
+    *family_base_rate = e.familyBaseRate;
+  }
+  if (ratio) {
+    *ratio = e.ratio;
+  }
+  CopyMessage(e.phase, phase, phasecap);
+  CopyMessage(e.path, path, pathcap);
+  if (config) {
+    FillConfig(e.filter->config(), config);
+  }
+  return MI_OK;
+}
+
+mi_filter *mi_bank_select(const mi_bank *b, unsigned input_rate, unsigned ratio, const char *phase, char *err,
+                          size_t errcap) {
+  return Guard(
+      [&]() -> mi_filter * {
+        if (!b) {
+          Fail(MI_ERR_ARG, "null bank", err, errcap);
+          return nullptr;
+        }
+        std::string error;
+        const auto *e = b->bank->Find(input_rate, ratio, phase ? phase : "min", &error);
+        if (!e) {
+          Fail(MI_ERR_FILTER, error, err, errcap);
+          return nullptr;
+        }
+        CopyMessage("", err, errcap);
+        return new mi_filter{e->filter};
+      },
+      nullptr);
+}
 
 }  // extern "C"

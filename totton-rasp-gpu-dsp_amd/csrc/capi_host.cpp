@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -11,7 +12,15 @@
 #include "host/eq.h"
 #include "host/filter_config.h"
 #include "host/filter_selector.h"
+#include "host/negotiation.h"
+#include "host/pcm_ring.h"
+#include "host/runtime_config.h"
+#include "host/stream_loop.h"
 #include "host/spectrum.h"
+
+struct mi_ring {
+  miups::PcmRing ring;
+};
 
 struct mi_tables {
   miups::FilterTables tables;
@@ -294,5 +303,134 @@ int mi_fused_set_of_block(int block, int log2k) { return miups::FusedSetOfBlock(
 int mi_fused_block_a(int tau, int log2k) { return miups::FusedBlockA(tau, log2k); }
 
 void mi_tables_free(mi_tables *t) { delete t; }
+
+
+// ---- negotiation -------------------------------------------------------------------------------------------
+int mi_rate_family(int sample_rate) { return static_cast<int>(miups::GetRateFamily(sample_rate)); }
+int mi_same_family(int a, int b) { return miups::IsSameFamily(a, b) ? 1 : 0; }
+int mi_upsample_ratio(int input_rate, int output_rate) { return miups::CalculateUpsampleRatio(input_rate, output_rate); }
+
+int mi_negotiate(int input_rate, int dac_valid, int dac_min_rate, int dac_max_rate, const int *dac_rates, size_t n_rates,
+                 int current_output_rate, mi_negotiated *out) {
+  if (!out) {
+    return MI_ERR_ARG;
+  }
+  miups::DacRates dac;
+  dac.valid = dac_valid != 0;
+  dac.minRate = dac_min_rate;
+  dac.maxRate = dac_max_rate;
+  if (dac_rates && n_rates) {
+    dac.rates.assign(dac_rates, dac_rates + n_rates);
+  }
+  if (!dac.valid) {
+    dac.errorMessage = "Device not found";
+  }
+  const miups::Negotiated n = miups::Negotiate(input_rate, dac, current_output_rate);
+  out->input_rate = n.inputRate;
+  out->family = static_cast<int>(n.family);
+  out->output_rate = n.outputRate;
+  out->ratio = n.ratio;
+  out->valid = n.valid ? 1 : 0;
+  out->requires_reconfiguration = n.requiresReconfiguration ? 1 : 0;
+  Put(n.errorMessage, out->error, sizeof(out->error));
+  return MI_OK;
+}
+
+// ---- config.json -------------------------------------------------------------------------------------------
+int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char *err, size_t errcap) {
+  if (!json_text || !out) {
+    Put("null argument", err, errcap);
+    return MI_ERR_ARG;
+  }
+  miups::RuntimeConfig c;
+  std::string error;
+  if (!miups::ParseRuntimeConfig(json_text, &c, &error)) {
+    Put(error, err, errcap);
+    return MI_ERR_FILTER;
+  }
+  std::memset(out, 0, sizeof(*out));
+  out->eq_enabled = c.eqEnabled ? 1 : 0;
+  Put(c.eqProfile, out->eq_profile, sizeof(out->eq_profile));
+  Put(c.eqProfilePath, out->eq_profile_path, sizeof(out->eq_profile_path));
+  out->ratio = c.ratio;
+  Put(c.phaseType, out->phase_type, sizeof(out->phase_type));
+  Put(c.filterDirectory, out->filter_directory, sizeof(out->filter_directory));
+  out->sample_rate = c.sampleRate;
+  out->channels = c.channels;
+  out->period_frames = c.periodFrames;
+  out->buffer_frames = c.bufferFrames;
+  Put(c.format, out->format, sizeof(out->format));
+  Put(c.inputDevice, out->input_device, sizeof(out->input_device));
+  Put(c.outputDevice, out->output_device, sizeof(out->output_device));
+  Put("", err, errcap);
+  return MI_OK;
+}
+
+// ---- ring --------------------------------------------------------------------------------------------------
+mi_ring *mi_ring_create(size_t capacity_bytes) {
+  if (capacity_bytes == 0) {
+    return nullptr;
+  }
+  mi_ring *r = new (std::nothrow) mi_ring();
+  if (r) {
+    r->ring.Init(capacity_bytes);
+  }
+  return r;
+}
+void mi_ring_destroy(mi_ring *r) { delete r; }
+int mi_ring_write(mi_ring *r, const void *data, size_t bytes) { return r && data && r->ring.Write(data, bytes) ? 1 : 0; }
+int mi_ring_read(mi_ring *r, void *dst, size_t bytes) { return r && dst && r->ring.Read(dst, bytes) ? 1 : 0; }
+size_t mi_ring_available_to_read(const mi_ring *r) { return r ? r->ring.AvailableToRead() : 0; }
+size_t mi_ring_available_to_write(const mi_ring *r) { return r ? r->ring.AvailableToWrite() : 0; }
+void mi_ring_clear(mi_ring *r) {
+  if (r) {
+    r->ring.Clear();
+  }
+}
+
+// ---- streaming loop ----------------------------------------------------------------------------------------
+int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn write, mi_process_fn process,
+                       mi_between_fn between, mi_log_fn log, void *user, const volatile int *running,
+                       mi_loop_stats *stats) {
+  if (!p || !read || !write) {
+    return MI_ERR_ARG;
+  }
+  miups::LoopParams lp;
+  lp.channels = p->channels;
+  lp.format = p->format;
+  lp.periodFrames = p->period_frames;
+  lp.blockInFrames = p->block_in_frames;
+  lp.blockOutFrames = p->block_out_frames;
+  lp.maxBlocksPerCall = p->max_blocks_per_call;
+  lp.drainAtEnd = p->drain_at_end != 0;
+  miups::LoopStats st;
+  miups::ProcessFn proc;
+  if (process) {
+    proc = [&](const void *in, void *out, std::size_t blocks) { return process(user, in, out, blocks) != 0; };
+  }
+  miups::BetweenBlocksFn btw;
+  if (between) {
+    btw = [&]() { between(user); };
+  }
+  const bool ok = miups::RunStreamLoop(
+      lp, [&](void *dst, std::size_t frames) { return read(user, dst, frames); },
+      [&](const void *src, std::size_t frames) { return write(user, src, frames) != 0; }, proc, btw,
+      [&]() { return !running || *running != 0; }, &st,
+      [&](const std::string &m) {
+        if (log) {
+          log(user, m.c_str());
+        }
+      });
+  if (stats) {
+    stats->periods_read = st.periodsRead;
+    stats->blocks_processed = st.blocksProcessed;
+    stats->frames_written = st.framesWritten;
+    stats->silence_frames_written = st.silenceFramesWritten;
+    stats->input_overflows = st.inputOverflows;
+    stats->output_overflows = st.outputOverflows;
+    stats->process_calls = st.processCalls;
+  }
+  return ok ? MI_OK : MI_ERR_DEVICE;
+}
 
 }  // extern "C"

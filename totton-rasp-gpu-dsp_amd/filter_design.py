@@ -67,17 +67,21 @@ def design_linear(n_taps: int, ratio: int, input_rate: int, passband_end: float,
 
 
 def minimum_phase_homomorphic(h_linear: np.ndarray) -> np.ndarray:
-    """Cepstral folding (same maths as scipy.signal.minimum_phase(method=
-    'homomorphic') with the reference's n_fft); output length (len+1)//2."""
+    """Cepstral folding, step for step what the reference's call computes
+    (scipy.signal.minimum_phase(h, method='homomorphic', n_fft=2^ceil(log2(8 len))), generate_minimum_phase.py:67-86):
+    |H| on the n_fft grid, a floor of 1e-7 x the smallest non-zero magnitude ADDED before the log, half the log
+    (the square root of the magnitude response), the causal cepstrum window 1, 2, ..., 2, 0, ..., 0 (for an even
+    n_fft the Nyquist term is dropped), exp of its transform; output length (len+1)//2."""
     n_fft = 2 ** int(math.ceil(math.log2(len(h_linear) * 8)))
-    spec = np.abs(np.fft.fft(h_linear, n_fft))
-    spec = np.maximum(spec, 1e-7 * spec[spec > 0].min())
-    ceps = np.fft.ifft(0.5 * np.log(spec)).real
-    fold = np.zeros_like(ceps)
-    fold[0] = ceps[0]
-    fold[1 : n_fft // 2] = 2.0 * ceps[1 : n_fft // 2]
-    fold[n_fft // 2] = ceps[n_fft // 2]
-    h_min = np.fft.ifft(np.exp(np.fft.fft(fold))).real
+    mag = np.abs(np.fft.fft(h_linear, n_fft))
+    mag += 1e-7 * mag[mag > 0].min()
+    ceps = np.fft.ifft(0.5 * np.log(mag)).real
+    win = np.zeros(n_fft)
+    win[0] = 1.0
+    win[1 : n_fft // 2] = 2.0
+    if n_fft % 2:
+        win[n_fft // 2] = 1.0
+    h_min = np.fft.ifft(np.exp(np.fft.fft(ceps * win))).real
     return h_min[: (len(h_linear) + 1) // 2]
 
 
@@ -105,6 +109,56 @@ def design(n_taps: int, ratio: int, family: str = "44k", phase: str = "min", pas
     return normalize_dc(h, ratio)
 
 
+def validate(h: np.ndarray, ratio: int, input_rate: int, passband_end: float, stopband_start: float,
+             target_stopband_db: float = 140.0) -> dict:
+    """The reference validator's metrics (scripts/filters/generate_filter.py:373-417): 16384-point response on
+    [0, fs_out/2); pass-band ripple = max - min dB up to passband_end; stop-band attenuation = |min dB| from
+    stopband_start up (sic: the reference takes the MINIMUM of the stop-band, i.e. its deepest point); peak position,
+    first/second-half energy ratio, minimum-phase and symmetry flags."""
+    from scipy import signal
+
+    h = np.asarray(h, dtype=np.float64)
+    w, H = signal.freqz(h, worN=16384, fs=input_rate * ratio)
+    H_db = 20 * np.log10(np.abs(H) + 1e-12)
+    pb = w <= passband_end
+    sb = w >= stopband_start
+    peak_idx = int(np.argmax(np.abs(h)))
+    mid = len(h) // 2
+    energy_ratio = float(np.sum(h[:mid] ** 2) / (np.sum(h[mid:] ** 2) + 1e-12))
+    peak_threshold = int(len(h) * 0.01)
+    stop = float(np.min(H_db[sb]))
+    peak = float(np.max(np.abs(H[pb]))) if pb.any() else 0.0
+    return {
+        "passband_ripple_db": float(np.max(H_db[pb]) - np.min(H_db[pb])),
+        "input_band_peak": peak,
+        "input_band_peak_normalized": peak / ratio if ratio else 0.0,
+        "stopband_attenuation_db": abs(stop),
+        "peak_position": peak_idx,
+        "peak_threshold_samples": peak_threshold,
+        "energy_ratio_first_to_second_half": energy_ratio,
+        "meets_stopband_spec": abs(stop) >= target_stopband_db,
+        "is_minimum_phase": bool(peak_idx < peak_threshold and energy_ratio > 10),
+        "is_symmetric": bool(np.allclose(h, h[::-1], atol=1e-10)),
+        "actual_taps": int(len(h)),
+    }
+
+
+def normalization_info(h_before: np.ndarray, h_after: np.ndarray, ratio: int, factor: float = 0.99) -> dict:
+    """The reference's normalisation record (generate_filter.py:473-519)."""
+    dc0 = float(np.sum(h_before))
+    return {
+        "original_dc_gain": dc0,
+        "target_dc_gain": float(ratio),
+        "dc_gain_factor": factor,
+        "normalized_dc_gain": float(np.sum(h_after)),
+        "applied_scale": float(ratio * factor / dc0),
+        "l1_norm": float(np.sum(np.abs(h_after))),
+        "l1_norm_ratio": float(np.sum(np.abs(h_after)) / ratio),
+        "max_coefficient_amplitude": float(np.max(np.abs(h_after))),
+        "normalization_applied": True,
+    }
+
+
 def export(h: np.ndarray, out_dir, name: str, ratio: int, extra: dict | None = None) -> Path:
     out = Path(out_dir)
     out.mkdir(parents=True, exist_ok=True)
@@ -129,10 +183,14 @@ def main(argv=None) -> int:
     a = ap.parse_args(argv)
     h = design(a.taps, a.ratio, a.family, a.phase, beta=a.kaiser_beta)
     input_rate, stop = MULTI_RATE[f"{a.family}_{a.ratio}x"]
+    results = validate(h, a.ratio, input_rate, 20000, stop)
     meta = dict(generation_date=datetime.now().isoformat(), n_taps_specified=a.taps, n_taps_actual=int(len(h)),
                 sample_rate_input=input_rate, sample_rate_output=input_rate * a.ratio, upsample_ratio=a.ratio,
-                passband_end_hz=20000, stopband_start_hz=stop, kaiser_beta=a.kaiser_beta,
-                dc_gain=float(np.sum(h.astype(np.float32))), generator="totton-rasp-gpu-dsp_amd/filter_design.py")
+                passband_end_hz=20000, stopband_start_hz=stop, target_stopband_attenuation_db=140,
+                kaiser_beta=a.kaiser_beta, minimum_phase_method="homomorphic" if a.phase == "min" else None,
+                target_dc_gain=float(a.ratio), output_basename=base_name(a.family, a.ratio, a.taps, a.phase),
+                validation_results=results, dc_gain=float(np.sum(h.astype(np.float32))),
+                generator="totton-rasp-gpu-dsp_amd/filter_design.py")
     p = export(h, a.out_dir, base_name(a.family, a.ratio, a.taps, a.phase), a.ratio, meta)
     print(p)
     return 0
