@@ -2,31 +2,34 @@
 """Headline benchmark: output Msamples/s of the 80k-tap overlap-save upsampler.
 
     python bench.py --gpus N --steps K --warmup W        (N = 1 by default)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* = one pass of the hot path over one batch of synthetic PCM that is
-already resident in HBM: `mi_engine_process_device` on interleaved s32 frames
-(fused kernel: PCM load -> FFT -> spectral multiply -> P inverse FFTs ->
+With N > 1 and no launcher the script starts N fresh child processes itself (one rank per GPU, before anything
+touches HIP in the parent); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it
+uses the ranks the launcher made. Either way a run with more ranks than visible devices fails loudly.
+
+A *step* = one pass of the hot path over one batch of synthetic PCM that is already resident in HBM:
+`mi_engine_process_device` on interleaved s32 frames (PCM load -> FFT -> spectral multiply -> P inverse FFTs ->
 overlap-discard -> PCM store, plus the small history-carry kernel).
 
-Workload at N = 1 is BASELINE.json configs[1]: 44.1k -> 176.4k (4x), stereo,
-80 001-tap minimum-phase filter, 2048 blocks per channel per launch. The path shards by
-independent streams: with N ranks every rank runs its own stereo
-stream(s) of the same size on its own GPU -- no data-path collective -- so the
-scaling is *weak*; torch.distributed (gloo) is used only for the rendezvous, the
-barriers around the timed region and the max-over-ranks of the elapsed time.
+Workload at N = 1 is BASELINE.json configs[1]: 44.1k -> 176.4k (4x), stereo, 80 001-tap minimum-phase filter, 256 blocks
+per channel per launch as BASELINE.md section 4 states it. The path shards by independent streams: with N
+ranks every rank runs its own stream(s) of the same size on its own GPU -- no data-path collective -- so the scaling is
+*weak*; torch.distributed (gloo) is used only for the rendezvous, the barriers around the timed region and the
+max-over-ranks of the elapsed and kernel times.
 
-Printed on rank 0 as ONE JSON line; `roofline` prices the fused kernel's
-ALGORITHMIC bytes (4B(1+1/L) per channel-block + the filter
-half-spectrum once per launch) against the 8 TB/s HBM peak using the kernel's
-own hipEvent duration on the launching stream; `cpu_baseline` times the
-reference's own C++ (oracle/_ref, built from /root/reference in the build
-container) -- or the C restatement when that library is absent -- on one host
-core over a bounded sample of the same workload.
+ONE JSON line on rank 0. Besides the contract's fields:
+  roofline      ALGORITHMIC bytes (4B(1+1/L) per channel-block + the filter half-spectrum once per launch)
+                over the kernels' own hipEvent duration on the launching stream, against the 8 TB/s HBM peak; `traffic`
+                = HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json)
+  variants      the same workload at 2048 blocks per launch, and a ~2 s sustained run of the headline launch
+  configs       BASELINE configs[1..4] (ids 2-5), each with value / ms / kernel ms / roofline (N = 1 only)
+  end_to_end    PCIe-inclusive rate of mi_engine_process_host on pinned host buffers (H2D, kernels, D2H overlapped)
+  cpu_baseline  the reference's own C++ (oracle/_ref) -- or the C restatement when that library is absent -- on one
+                core AND on all cores of this host (one channel per process), plus the config-1 scipy.signal.fftconvolve
+                leg (stereo 8192-frame block, zero-stuffed 2x, 80 001 taps)
 
-`--dry-run` exercises everything except the GPU (rank/stream sharding,
-rendezvous, barriers, max-reduce, JSON assembly) with a synthetic per-rank
-time; tests/test_distributed.py uses it with world_size 2 on CPU.
+`--dry-run` exercises everything except the GPU (rank/stream sharding, rendezvous, barriers, max-reduce, JSON
+assembly) with a synthetic per-rank time; tests/test_distributed.py uses it with world_size 2 on CPU.
 """
 from __future__ import annotations
 
@@ -34,6 +37,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -46,14 +51,13 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {
-    # id: (filter file, streams per GPU, channels, blocks per channel, description)
-    # 2048 blocks = 9.9 min of 44.1 kHz stereo per launch: 8 rounds of workgroups on 256 CUs (a one-round
-    # launch of 256 blocks is 10-15 % slower: lockstep memory phases, launch gap; profiles/r01_summary.md)
-    2: ("filter_44k_4x_80000_min_phase.json", 1, 2, 2048, "44.1k->176.4k 4x stereo, 80k-tap min-phase"),
+    # id: (filter file, streams per GPU, channels, blocks per channel, description)   [BASELINE.md section 4]
+    2: ("filter_44k_4x_80000_min_phase.json", 1, 2, 256, "44.1k->176.4k 4x stereo, 80k-tap min-phase"),
     3: ("filter_48k_16x_80000_min_phase.json", 1, 8, 256, "48k->768k 16x 8ch, 80k-tap min-phase + EQ"),
     4: ("filter_44k_2x_80000_min_phase.json", 32, 2, 32, "32 stereo streams/GPU, 44.1k 2x 80k-tap"),
     5: ("filter_48k_8x_160000_linear_phase.json", 1, 32, 64, "48k 8x linear 160k-tap, 32ch + EQ"),
 }
+LONG_BLOCKS = 2048  # the headline workload as 8 rounds of workgroups per launch (9.9 min of audio)
 
 EQ_PROFILE = ROOT / "tests" / "golden" / "g4_eq_profiles.json"
 
@@ -80,6 +84,9 @@ class Hip:
         self.check(self.lib.hipMalloc(C.byref(p), n), "hipMalloc")
         return p.value
 
+    def free(self, p):
+        self.check(self.lib.hipFree(C.c_void_p(p)), "hipFree")
+
     def h2d(self, dst, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.hipMemcpy(dst, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy H2D")
@@ -97,27 +104,45 @@ class Hip:
 
 
 def stream_ids(rank: int, streams_per_gpu: int) -> list[int]:
-    """Global ids of the independent streams rank `rank` owns (SURVEY §8e: static
+    """Global ids of the independent streams rank `rank` owns (SURVEY 8e: static
     partition by stream, nothing shared between ranks but the read-only filter)."""
     return [rank * streams_per_gpu + s for s in range(streams_per_gpu)]
 
 
 def synth_pcm(config_id: int, stream_id: int, frames: int, channels: int) -> np.ndarray:
-    """SURVEY §8d: round(clip(0.2*N(0,1), -1, 1) * 2^31), seed 1000*config + stream."""
+    """SURVEY 8d: round(clip(0.2*N(0,1), -1, 1) * 2^31), seed 1000*config + stream."""
     rng = np.random.default_rng(1000 * config_id + stream_id)
     x = np.clip(rng.standard_normal((frames, channels)) * 0.2, -1.0, 1.0)
     return np.clip(np.round(x * 2147483648.0), -2147483648, 2147483647).astype("<i4")
 
 
-def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
-    """Reference C++ (or its C restatement) on ONE host core, one channel of the
-    same workload, for about `budget_s` seconds."""
+def algorithmic_bytes(cfg: dict, units: int) -> float:
+    """units * 4B(1 + 1/L) + the filter half-spectrum 8(N/2+1) once per launch."""
+    return units * 4.0 * cfg["block_size"] * (1.0 + 1.0 / cfg["upsample_factor"]) + 8.0 * (cfg["fft_size"] // 2 + 1)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines --
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_worker(filter_path: str, budget_s: float, seed: int):
+    """One core, one channel of the headline workload through ProcessBlock for `budget_s` seconds.
+    Returns (blocks, seconds, kind). Top-level so that multiprocessing (spawn) can import it."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as O
 
     h, taps, fft, block, L = O.read_filter(filter_path)
     nin = block // L
-    x = (np.random.default_rng(7).standard_normal(nin) * 0.2).astype(np.float32)
+    x = (np.random.default_rng(seed).standard_normal(nin) * 0.2).astype(np.float32)
     if O.have_ref():
         u = O.RefUpsampler()
         ok, msg = u.load_filter(filter_path)
@@ -134,50 +159,200 @@ def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
         assert y.size == block
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s and n >= 16:
+        if dt >= budget_s and n >= 8:
             break
-    return {"value": round(n * block / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "host_cores_available": os.cpu_count(),
-            "sample": f"{n} blocks x 1 channel of the same filter/geometry through ProcessBlock "
-                      f"({'oracle/_ref = reference C++ CPU path' if kind == 'reference' else 'oracle C restatement'}, "
-                      f"{dt:.1f} s, single thread)"}
+    return n, dt, kind, block
 
 
-def run_gpu(args, ups, cfg, fpath, rank, local_rank, streams, channels, blocks, barrier):
-    """Timed region on this rank's GPU. Returns (elapsed_s, kernel stats, engine path)."""
-    hip = Hip()
-    device = local_rank % ups.device_count()
-    hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
-    filt = ups.Filter(fpath, device=device)
-    use_eq = args.eq or args.config in (3, 5)
-    if use_eq:
-        text = json.loads(EQ_PROFILE.read_text())["opra10"]
-        filt.set_eq(text, 768000.0 if "48k" in fpath.name else 705600.0)
-    eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
-    # synthetic PCM, resident in HBM before anything is timed
-    in_stride, out_stride = eng.in_bytes(blocks), eng.out_bytes(blocks)
-    d_in = hip.malloc(in_stride * streams)
-    d_out = hip.malloc(out_stride * streams)
-    for s, sid in enumerate(stream_ids(rank, streams)):
-        hip.h2d(d_in + s * in_stride, synth_pcm(args.config, sid, blocks * eng.in_frames, channels))
-    stream = hip.stream()
-    for _ in range(args.warmup):
-        eng.process_device(d_in, d_out, blocks, stream)
-    eng.enable_kernel_timing(max(args.steps, 1))
-    hip.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.process_device(d_in, d_out, blocks, stream)
-    hip.sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    kstat = eng.kernel_ms_stats()
-    # sanity on the last output (not timed): non-trivial
-    tail = np.empty(min(cfg["block_size"] * channels, 65536), dtype="<i4")
-    hip.d2h(tail, d_out)
-    assert np.abs(tail.astype(np.int64)).max() > 0, "output is all zeros"
-    return elapsed, kstat, eng.path, use_eq
+def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
+    """(1) one core, (2) all cores -- one channel per process, nothing shared --, (3) BASELINE configs[0]: the
+    scipy.signal.fftconvolve plumbing leg. About budget_s seconds for each of (1) and (2)."""
+    import multiprocessing as mp
+
+    n1, dt1, kind, block = _cpu_worker(str(filter_path), budget_s, 7)
+    one = n1 * block / dt1 / 1e6
+    cores = host_cores()
+    what = "oracle/_ref = reference C++ CPU path" if kind == "reference" else "oracle C restatement"
+    res = {"value": round(one, 4), "unit": "Msamples/s", "cores": 1, "kind": kind,
+           "sample": f"{n1} blocks x 1 channel of the headline filter/geometry through ProcessBlock ({what}, {dt1:.1f} s, "
+                     "single thread)",
+           "host_cores_available": cores, "host_cpu_count": os.cpu_count()}
+    if cores > 1:
+        ctx = mp.get_context("spawn")  # fresh interpreters: nothing of this process (HIP included) is inherited
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            parts = pool.starmap(_cpu_worker, [(str(filter_path), budget_s, 100 + i) for i in range(cores)])
+        wall = time.perf_counter() - t0
+        rate = sum(n * b / dt for n, dt, _, b in parts) / 1e6
+        res["all_cores"] = {"value": round(rate, 3), "unit": "Msamples/s", "cores": cores, "kind": kind,
+                            "sample": f"{sum(p[0] for p in parts)} blocks over {cores} processes, one channel each, "
+                                      f"{budget_s:.0f} s of ProcessBlock per process ({wall:.1f} s wall incl. start-up)"}
+    try:
+        from scipy.signal import fftconvolve
+
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import oracle as O
+
+        p2 = ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.json"
+        h2 = O.read_filter(p2)[0]
+        x = (np.random.default_rng(1000).standard_normal((8192, 2)) * 0.2)
+        leg = {}
+        for name, dt_ in (("f32", np.float32), ("f64", np.float64)):
+            up = np.zeros((16384, 2), dt_)
+            up[::2] = x.astype(dt_)
+            hh = h2.astype(dt_)
+            fftconvolve(up[:, 0], hh)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0 or n < 5:
+                for c in range(2):
+                    y = fftconvolve(up[:, c], hh)
+                n += 1
+            dt = (time.perf_counter() - t0) / n
+            leg[name] = {"ms_per_block": round(dt * 1e3, 3), "Msamples_per_s": round(16384 * 2 / dt / 1e6, 3)}
+        res["fftconvolve_config1"] = {"workload": "configs[0]: 44.1k->88.2k 2x stereo, one 8192-frame block zero-stuffed 2x, "
+                                                  "80 001 taps, scipy.signal.fftconvolve per channel, 1 thread", **leg}
+    except ImportError:
+        res["fftconvolve_config1"] = "scipy unavailable on this host"
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------- GPU runs --
+class Workload:
+    """One config resident on this rank's GPU: filter (+EQ), engine, synthetic PCM in HBM."""
+
+    def __init__(self, ups, hip, device, config_id, rank, streams=None, blocks=None, eq=None):
+        fname, s, channels, b, desc = CONFIGS[config_id]
+        self.config_id, self.desc, self.fname = config_id, desc, fname
+        self.streams, self.channels, self.blocks = streams or s, channels, blocks or b
+        self.fpath = ROOT / "data" / "coefficients" / fname
+        ok, msg, cfg = ups.read_filter(self.fpath)
+        if not ok:
+            raise RuntimeError(msg)
+        self.cfg = cfg
+        self.hip = hip
+        self.filt = ups.Filter(self.fpath, device=device)
+        self.use_eq = (config_id in (3, 5)) if eq is None else eq
+        if self.use_eq:
+            text = json.loads(EQ_PROFILE.read_text())["opra10"]
+            self.filt.set_eq(text, 768000.0 if "48k" in fname else 705600.0)
+        self.eng = ups.Engine(self.filt, self.streams, channels, ups.PCM_S32, ups.PCM_S32)
+        self.in_stride, self.out_stride = self.eng.in_bytes(self.blocks), self.eng.out_bytes(self.blocks)
+        self.d_in = hip.malloc(self.in_stride * self.streams)
+        self.d_out = hip.malloc(self.out_stride * self.streams)
+        for i, sid in enumerate(stream_ids(rank, self.streams)):
+            hip.h2d(self.d_in + i * self.in_stride, synth_pcm(config_id, sid, self.blocks * self.eng.in_frames, channels))
+        self.stream = hip.stream()
+
+    @property
+    def units(self):
+        return self.blocks * self.streams * self.channels
+
+    def run(self, steps, warmup, barrier=lambda: None, min_seconds=0.0):
+        """W untimed steps, then K (or at least min_seconds of) timed steps. Returns (steps done, elapsed s, kernel stats)."""
+        for _ in range(warmup):
+            self.eng.process_device(self.d_in, self.d_out, self.blocks, self.stream)
+        self.eng.enable_kernel_timing(64 if min_seconds else max(steps, 1))
+        self.hip.sync()
+        barrier()
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for _ in range(steps):
+                self.eng.process_device(self.d_in, self.d_out, self.blocks, self.stream)
+            done += steps
+            if not min_seconds:
+                break
+            self.hip.check(self.hip.lib.hipStreamSynchronize(C.c_void_p(self.stream)), "hipStreamSynchronize")
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+        self.hip.sync()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        return done, elapsed, self.eng.kernel_ms_stats()
+
+    def check_output(self):
+        tail = np.empty(min(self.cfg["block_size"] * self.channels, 65536), dtype="<i4")
+        self.hip.d2h(tail, self.d_out)
+        assert np.abs(tail.astype(np.int64)).max() > 0, "output is all zeros"
+
+    def close(self):
+        self.hip.sync()
+        self.eng.close()
+        self.filt.close()
+        self.hip.free(self.d_in)
+        self.hip.free(self.d_out)
+
+
+def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
+    samples = w.units * w.cfg["block_size"] * world * steps
+    bytes_launch = algorithmic_bytes(w.cfg, w.units)
+    achieved = bytes_launch / (kstat["avg"] * 1e-3) / 1e9 if kstat["avg"] > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms_avg": round(kstat["avg"], 5),
+            "kernel_ms_min": round(kstat["min"], 5), "kernel_launches_timed": kstat["count"],
+            "algorithmic_bytes_per_launch": int(bytes_launch)}
+    key = str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks"
+    rec = (traffic or {}).get(key)
+    if rec and (rec["streams"], rec["channels"], rec["blocks"]) == (w.streams, w.channels, w.blocks):
+        roof["traffic"] = int(rec["bytes"])
+        roof["traffic_over_algorithmic"] = round(rec["bytes"] / bytes_launch, 3)
+        roof["traffic_source"] = rec["source"] + " (separate rocprofv3 --pmc passes; 2*FETCH_SIZE + WRITE_SIZE)"
+    return {"value": round(samples / elapsed / 1e6, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "roofline": roof}
+
+
+def config_block(w: Workload) -> dict:
+    return {"workload": f"configs[{w.config_id - 1}]: {w.desc}", "filter": w.fname, "taps": w.cfg["taps"],
+            "fft_size": w.cfg["fft_size"], "block_size": w.cfg["block_size"], "upsample_factor": w.cfg["upsample_factor"],
+            "streams_per_gpu": w.streams, "channels": w.channels, "blocks_per_channel": w.blocks,
+            "pcm": "s32 interleaved in/out", "eq": bool(w.use_eq), "kernel_path": w.eng.path}
+
+
+def end_to_end(ups, w: Workload, seconds=2.0) -> dict:
+    """mi_engine_process_host on PINNED host buffers: sub-batches of the call overlap H2D, kernels and D2H."""
+    pin_in = ups.PinnedBuffer(w.in_stride * w.streams)
+    pin_out = ups.PinnedBuffer(w.out_stride * w.streams)
+    x = np.concatenate([synth_pcm(w.config_id, sid, w.blocks * w.eng.in_frames, w.channels).reshape(-1)
+                        for sid in range(w.streams)])
+    pin_in.array[:] = x.view(np.uint8)
+    for _ in range(2):
+        w.eng.process_host(pin_in.array, w.blocks, out=pin_out.array)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or n < 3:
+        w.eng.process_host(pin_in.array, w.blocks, out=pin_out.array)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    host_bytes = pin_in.array.nbytes + pin_out.array.nbytes
+    res = {"value": round(w.units * w.cfg["block_size"] / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(dt * 1e3, 4),
+           "host_link_GB_per_s": round(host_bytes / dt / 1e9, 2), "host_bytes_per_call": int(host_bytes), "calls_timed": n,
+           "boundary": "mi_engine_process_host, pinned host buffers (mi_host_alloc), sub-batches pipelined over three "
+                       "HIP streams with double-buffered device staging",
+           "workload": f"configs[{w.config_id - 1}] x {w.blocks} blocks/channel per call"}
+    pin_in.close()
+    pin_out.close()
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------- launching --
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher: N children, one rank each, rendezvous on 127.0.0.1. The parent
+    touches neither HIP nor torch; rank 0's stdout (the ONE json line) is the parent's."""
+    port = free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main() -> int:
@@ -185,31 +360,39 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="headline workload (default: configs[1])")
     ap.add_argument("--blocks", type=int, default=0, help="override blocks per channel")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eq", action="store_true", help="fold the 10-band EQ profile into the filter")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no variants / configs / end_to_end")
+    ap.add_argument("--eq", action="store_true", help="fold the 10-band EQ profile into the headline filter")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: synthetic per-rank time (CPU tests)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)  # nothing below has run yet in this process: no HIP, no torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`",
-                  file=sys.stderr)
-            return 2
-        args.gpus = world
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
 
     # product library first: it brings in the HIP runtime it was built against
     import totton_rasp_gpu_dsp_amd as ups
 
-    if not args.dry_run and ups.device_count() < 1:
-        print("bench.py: no HIP device (the upsampler has no CPU path)", file=sys.stderr)
-        return 1
+    if not args.dry_run:
+        # BENCH_VISIBLE_DEVICES_FOR_TEST: CPU test hook for the over-subscription check only (tests/test_distributed.py)
+        ndev = int(os.environ.get("BENCH_VISIBLE_DEVICES_FOR_TEST") or ups.device_count())
+        if ndev < 1:
+            print("bench.py: no HIP device (the upsampler has no CPU path)", file=sys.stderr)
+            return 1
+        if world > ndev:
+            # every rank sees the same count and stops here, before the rendezvous: nobody waits for a peer
+            print(f"bench.py: {world} ranks requested but only {ndev} HIP device(s) are visible; ranks are never "
+                  "stacked on one GPU", file=sys.stderr)
+            return 3
 
     dist = None
     if world > 1:
@@ -232,30 +415,50 @@ def main() -> int:
         if dist is not None:
             dist.barrier()
 
+    def reduce_max(v: float) -> float:
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    try:
+        traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    except (OSError, ValueError):
+        traffic = {}
+
     fname, streams, channels, blocks, desc = CONFIGS[args.config]
     streams = args.streams or streams
     blocks = args.blocks or blocks
-    fpath = ROOT / "data" / "coefficients" / fname
-    ok, msg, cfg = ups.read_filter(fpath)
-    if not ok:
-        print(f"bench.py: {msg}", file=sys.stderr)
-        return 1
-    L, B, N = cfg["upsample_factor"], cfg["block_size"], cfg["fft_size"]
-
+    extras = {}
     if args.dry_run:
+        ok, msg, cfg = ups.read_filter(ROOT / "data" / "coefficients" / fname)
+        if not ok:
+            print(f"bench.py: {msg}", file=sys.stderr)
+            return 1
         barrier()
         elapsed = 0.010 * (rank + 1)  # deterministic, rank-dependent: the max-reduce must pick the last rank
         barrier()
-        kstat = {"avg": elapsed * 1e3 / max(args.steps, 1), "min": 0.0, "count": 0}
-        path, use_eq = "dry-run", False
+        kavg = elapsed * 1e3 / max(args.steps, 1)
+        kstat = {"avg": kavg, "min": 0.0, "count": 0}
+        units = blocks * streams * channels
+        cblock = {"workload": f"configs[{args.config - 1}]: {desc}", "filter": fname, "taps": cfg["taps"],
+                  "fft_size": cfg["fft_size"], "block_size": cfg["block_size"], "upsample_factor": cfg["upsample_factor"],
+                  "streams_per_gpu": streams, "channels": channels, "blocks_per_channel": blocks,
+                  "pcm": "s32 interleaved in/out", "eq": False, "kernel_path": "dry-run"}
     else:
-        elapsed, kstat, path, use_eq = run_gpu(args, ups, cfg, fpath, rank, local_rank, streams, channels, blocks, barrier)
+        hip = Hip()
+        device = local_rank
+        hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
+        w = Workload(ups, hip, device, args.config, rank, streams, blocks, eq=True if args.eq else None)
+        _, elapsed, kstat = w.run(args.steps, args.warmup, barrier)
+        w.check_output()
+        units, cfg, cblock = w.units, w.cfg, config_block(w)
 
+    elapsed = reduce_max(elapsed)
+    kstat = dict(kstat, avg=reduce_max(kstat["avg"]))  # the slowest rank's kernels price the roofline
     owned = stream_ids(rank, streams)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         ids = [None] * world
         dist.all_gather_object(ids, owned)
         all_ids = sorted(i for part in ids for i in part)
@@ -263,50 +466,71 @@ def main() -> int:
         all_ids = owned
     assert all_ids == list(range(world * streams)), "stream partition must be disjoint and complete"
 
-    units_rank = blocks * streams * channels                 # channel-blocks per launch on this GPU
-    samples_step = units_rank * B * world                    # whole job, all ranks
-    value = samples_step * args.steps / elapsed / 1e6
-    bytes_unit = 4.0 * B * (1.0 + 1.0 / L)
-    bytes_launch = units_rank * bytes_unit + 8.0 * (N // 2 + 1)
-    achieved = bytes_launch / (kstat["avg"] * 1e-3) / 1e9
+    if args.dry_run:
+        samples = units * cfg["block_size"] * world * args.steps
+        bytes_launch = algorithmic_bytes(cfg, units)
+        achieved = bytes_launch / (kstat["avg"] * 1e-3) / 1e9
+        head = {"value": round(samples / elapsed / 1e6, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                             "kernel_ms_avg": round(kstat["avg"], 5), "kernel_ms_min": 0.0, "kernel_launches_timed": 0,
+                             "algorithmic_bytes_per_launch": int(bytes_launch)}}
+    else:
+        head = summary(w, args.steps, elapsed, kstat, world, traffic)
+
+    if not args.dry_run and world == 1 and not args.no_extras:
+        # the same workload as 8 rounds of workgroups per launch, and a sustained run of the headline launch
+        variants = {}
+        done, el, ks = w.run(max(args.steps, 1), 1, min_seconds=2.0)
+        s = summary(w, done, el, ks, 1, traffic)
+        variants["sustained"] = {"seconds": round(el, 3), "steps": done, "value": s["value"], "ms_per_step": s["ms_per_step"],
+                                 "kernel_ms_avg": s["roofline"]["kernel_ms_avg"], "frac": s["roofline"]["frac"]}
+        if args.config == 2 and not args.blocks:
+            wl = Workload(ups, hip, device, 2, rank, streams, LONG_BLOCKS, eq=True if args.eq else None)
+            _, el, ks = wl.run(args.steps, args.warmup)
+            s = summary(wl, args.steps, el, ks, 1, traffic)
+            variants[f"blocks_{LONG_BLOCKS}"] = {"blocks_per_channel": LONG_BLOCKS, "value": s["value"],
+                                                 "ms_per_step": s["ms_per_step"], "roofline": s["roofline"]}
+            wl.close()
+        extras["variants"] = variants
+        extras["end_to_end"] = end_to_end(ups, w)
+        rows = []
+        for cid in sorted(CONFIGS):
+            wc = w if cid == args.config and not (args.blocks or args.streams) else Workload(ups, hip, device, cid, rank)
+            _, el, ks = wc.run(args.steps, args.warmup)
+            s = summary(wc, args.steps, el, ks, 1, traffic)
+            rows.append({"id": cid, "config": config_block(wc), "value": s["value"], "unit": "Msamples/s",
+                         "ms_per_step": s["ms_per_step"], "roofline": s["roofline"]})
+            if wc is not w:
+                wc.close()
+        extras["configs"] = rows
+        extras["per_kernel_ms"] = ("hipEvent pair = all kernels of a call (planarize + transform + interleave where they "
+                                   "exist); the split per kernel is in profiles/r02_*_kernel_stats.csv (rocprofv3 --kernel-trace "
+                                   "--stats of this command)")
+
     result = {
         "metric": "output Msamples/s, 80k-tap FIR upsample (overlap-save), interleaved s32 PCM in HBM",
-        "value": round(value, 3),
+        "value": head["value"],
         "unit": "Msamples/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"configs[{args.config - 1}]: {desc}", "filter": fname, "taps": cfg["taps"],
-                   "fft_size": N, "block_size": B, "upsample_factor": L, "streams_per_gpu": streams,
-                   "channels": channels, "blocks_per_channel": blocks, "pcm": "s32 interleaved in/out",
-                   "eq": bool(use_eq), "kernel_path": path, "streams_total": world * streams,
-                   "parallelism": f"streams sharded over {world} GPU(s), no collective"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel_ms_avg": round(kstat["avg"], 5), "kernel_ms_min": round(kstat["min"], 5),
-                     "kernel_launches_timed": kstat["count"],
-                     "algorithmic_bytes_per_launch": int(bytes_launch),
-                     "note": "bytes = units*4B(1+1/L) + 8(N/2+1); duration = hipEvent pair around the "
-                             f"{path} kernel(s) on the launching stream, rank 0"},
+        "config": dict(cblock, streams_total=world * streams,
+                       parallelism=f"streams sharded over {world} GPU(s), no collective"),
+        "roofline": dict(head["roofline"],
+                         note="bytes = units*4B(1+1/L) + 8(N/2+1); duration = hipEvent pair around the call's kernels on the "
+                              "launching stream, max over ranks"),
     }
-    # HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json), when
-    # this run is the workload those passes measured
-    try:
-        rec = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(str(args.config))
-    except (OSError, ValueError):
-        rec = None
-    if rec and (rec["streams"], rec["channels"], rec["blocks"]) == (streams, channels, blocks) and not args.dry_run:
-        result["roofline"]["traffic"] = int(rec["bytes"])
-        result["roofline"]["traffic_source"] = rec["source"] + " (separate rocprofv3 --pmc passes; 2*FETCH_SIZE + WRITE_SIZE)"
+    result.update(extras)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
-            result["cpu_baseline"] = cpu_baseline(fpath, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(ROOT / "data" / "coefficients" / fname, args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

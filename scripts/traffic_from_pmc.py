@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC summaries of scripts/gpu_r02_measure.sh (gpurun_out/r02/pmc_<tag>.txt).
+
+HBM-side bytes per bench step = sum over the kernels of one mi_engine_process_device call of
+(2 * FETCH_SIZE + WRITE_SIZE) KiB x launches of that kernel per call. Unit of both counters: KiB. gfx950 correction per
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-B read requests at 64 B, so it is doubled; WRITE_SIZE as is."""
+import json
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+SRC = ROOT / "gpurun_out" / "r02"
+TAGS = {"c2_256": ("2", 1, 2, 256), "c2_2048": ("2_2048blocks", 1, 2, 2048), "c3": ("3", 1, 8, 256), "c4": ("4", 32, 2, 32),
+        "c5": ("5", 1, 32, 64)}
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in path.read_text().splitlines():
+        if line.startswith("== "):
+            cur = re.sub(r"^void ", "", line[3:].strip())
+            out[cur] = {}
+        elif cur and "mean" in line:
+            name, _, rest = line.strip().partition(" ")
+            m = re.search(r"mean\s+([0-9.]+)\s+\(n=(\d+)\)", line)
+            out[cur][name] = (float(m.group(1)), int(m.group(2)))
+    return out
+
+
+def main():
+    res = {"_comment": __doc__.strip().replace("\n", " ")}
+    for tag, (key, streams, channels, blocks) in TAGS.items():
+        k = parse(SRC / f"pmc_{tag}.txt")
+        calls = k["miups::update_history_kernel"]["FETCH_SIZE"][1]  # one per bench step
+        kernels, total = {}, 0.0
+        for name, c in k.items():
+            if not name.startswith("miups::") or "update_history" in name or "anonymous" in name or "FETCH_SIZE" not in c:
+                continue
+            per_call = c["FETCH_SIZE"][1] / calls
+            kib = (2 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * per_call
+            hit, miss = c.get("TCC_HIT_sum", (0, 0))[0], c.get("TCC_MISS_sum", (0, 0))[0]
+            kernels[name] = {"launches_per_step": per_call, "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
+                             "bytes_per_step": int(kib * 1024), "l2_hit_rate": round(hit / (hit + miss), 3) if hit + miss else None}
+            total += kib * 1024
+        res[key] = {"streams": streams, "channels": channels, "blocks": blocks, "bytes": int(total), "kernels": kernels,
+                    "source": f"profiles/r02_c_pmc_{tag}.txt"}
+        (ROOT / "profiles" / f"r02_c_pmc_{tag}.txt").write_text((SRC / f"pmc_{tag}.txt").read_text())
+    (ROOT / "profiles" / "traffic.json").write_text(json.dumps(res, indent=1) + "\n")
+    for key, v in res.items():
+        if key != "_comment":
+            print(key, v["bytes"], {n.split("<")[0][7:]: x["bytes_per_step"] for n, x in v["kernels"].items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -60,17 +60,68 @@ def test_two_ranks_gloo_contract(config, streams):
     assert roof["algorithmic_bytes_per_launch"] == int(per_launch + 8 * (cfg["fft_size"] // 2 + 1))
 
 
-def test_single_process_dry_run_and_flag_mismatch():
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run", "--steps", "2"], env=env,
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_single_process_dry_run():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run", "--steps", "2"], env=clean_env(),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.strip())
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["workload"].startswith("configs[1]")
-    # asking for 2 GPUs without the launcher is an error, not a silent N = 1 run
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 2 and "torch.distributed.run" in r.stderr
+    assert d["config"]["blocks_per_channel"] == 256          # BASELINE.md section 4 states 256 blocks per channel
+
+
+def test_plain_launch_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the script starts two fresh ranks itself (gloo rendezvous on
+    127.0.0.1), rank 0 prints the ONE line, the aggregate covers both ranks."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5"], env=clean_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["streams_total"] == 2
+    assert abs(d["ms_per_step"] - 20.0 / 5) < 1e-6           # MAX over ranks: rank 1's synthetic 20 ms
+
+
+def test_more_ranks_than_devices_fails_loudly_and_does_not_hang():
+    """Ranks are never stacked on one GPU: with 1 visible device a 2-rank run stops in every rank before the
+    rendezvous (exit 3, message), under the launcher-free start as well as under an external launcher."""
+    env = clean_env(BENCH_VISIBLE_DEVICES_FOR_TEST="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 3 and "2 ranks requested but only 1 HIP device(s) are visible" in r.stderr
+    assert r.stdout.strip() == ""
+    env = clean_env(BENCH_VISIBLE_DEVICES_FOR_TEST="1", RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                    MASTER_PORT=str(free_port()))
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 3 and "never stacked" in r.stderr
+    # --gpus that contradicts the launcher's WORLD_SIZE is an error, not a silent resize
+    env = clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_cpu_baseline_legs_on_this_host():
+    """The three CPU legs of the bench line, with a tiny budget: one core, all cores (one channel per process), and
+    the config-1 fftconvolve block."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    r = bench.cpu_baseline(ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json", 0.3)
+    assert r["cores"] == 1 and r["value"] > 0 and r["kind"] in ("reference", "port")
+    assert r["host_cores_available"] == bench.host_cores() >= 1
+    if r["host_cores_available"] > 1:
+        a = r["all_cores"]
+        assert a["cores"] == r["host_cores_available"] and a["value"] > r["value"]
+    f = r["fftconvolve_config1"]
+    assert f["f32"]["Msamples_per_s"] > 0 and f["f64"]["ms_per_block"] > 0 and "8192-frame" in f["workload"]
 
 
 def test_stream_partition_and_seeds():

@@ -151,6 +151,41 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     assert max(times[5:]) < 10 * typical + 5e-3, (max(times[5:]), typical, swaps)
 
 
+def test_calls_on_alternating_streams_are_ordered_by_the_engine(ups, gpu):
+    """Engine state (history double buffer, staging planes) is ordered by the engine, not by the caller's choice of
+    stream: the same 12 single-block calls issued alternately on two non-blocking-style streams, on the NULL stream and
+    interleaved with reset() give the bytes of the single-stream run."""
+    from bench import Hip
+
+    hip = Hip()
+    hip.check(hip.lib.hipSetDevice(gpu), "hipSetDevice")
+    filt = ups.Filter(F4X, device=gpu)
+    eng = ups.Engine(filt, 1, 2, ups.PCM_S32, ups.PCM_S32)
+    nb = 12
+    x = synth(1, nb * eng.in_frames, 2, seed=21)
+    d_in, d_out = hip.malloc(eng.in_bytes(nb)), hip.malloc(eng.out_bytes(nb))
+    hip.h2d(d_in, x)
+    ib, ob = eng.in_bytes(1), eng.out_bytes(1)
+    s0, s1 = hip.stream(), hip.stream()
+
+    def run(streams):
+        eng.reset()
+        for b in range(nb):
+            eng.process_device(d_in + b * ib, d_out + b * ob, 1, streams[b % len(streams)])
+        for s in set(streams):
+            hip.check(hip.lib.hipStreamSynchronize(C.c_void_p(s)), "sync")
+        hip.sync()
+        out = np.empty(eng.out_bytes(nb), np.uint8)
+        hip.d2h(out, d_out)
+        return out
+
+    want = run([s0])
+    np.testing.assert_array_equal(run([s0, s1]), want)
+    np.testing.assert_array_equal(run([s1, 0, s0]), want)
+    hip.free(d_in)
+    hip.free(d_out)
+
+
 # ---- resident spectra and switching -------------------------------------------------------------------------------
 def test_filter_bank_resident_filters_and_rebind(ups, O, gpu):
     bank = ups.FilterBank(ROOT / "data" / "coefficients", device=gpu)
