@@ -122,7 +122,7 @@ cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
 template <int LOG2K>
 void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr};
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr, t.Wself};
   if (io.ext_epilogue) {
     miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true>(g, io, ft); });
   } else {
@@ -133,7 +133,7 @@ void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsign
 template <int LOG2K>
 void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, t.selfW.data()};
+  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, t.selfW.data(), t.Wself};
   miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
 }
 

@@ -83,7 +83,7 @@ MI_DEVICE cf mk(float x, float y) {
 // SLOWER (config 2: 190 -> 179, config 5: 168 -> 163 Gsamples/s, same box, interleaved runs). The product therefore
 // compiles this source to scalar instructions; -DMIUPS_EXP_PACKED_MATH (experiment switch) selects the packed form.
 // The emulation build (g++, tests/emu) uses the scalar form too.
-#if defined(MIUPS_HOST_EMU) || defined(MIUPS_EXP_SCALAR_MATH)
+#if defined(MIUPS_HOST_EMU) || !defined(MIUPS_EXP_PACKED_MATH)
 struct v2 {
   float x, y;
 };
@@ -162,11 +162,14 @@ struct FusedTables {
   const cf *tw;        // Stockham/Cooley-Tukey pass twiddles, see tw_offset()
   const cf *WmT;       // [T]            W_M^a                     (a = low index of the thread's first set)
   const int *blockB;   // [T]            LDS block that holds the thread's second set after the forward FFT
-  const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau)
-  const f4 *G0;        // [P][17]        thread 0: k = t*J (t = 0..8) then k = J/2 + t*J (t = 0..7)
+  const f4 *GT;        // [P][16][T]     {Gs[k], Gc[k]}, k = a + t*J  (pair t of thread tau); column 0 = thread 0's slots:
+                       //                slot t <= 8: k = t*J, slot t >= 9: k = J/2 + (t-9)*J
+  const f4 *G0;        // [P][17]        thread 0's 17 pairs: k = t*J (t = 0..8) then k = J/2 + t*J (t = 0..7); the kernel
+                       //                reads entry 16 (its extra pair), the rest documents column 0 of GT
   cf Wb;               // W_M^(J/2)
   // split form (fused_split_kernel) instead: GT [P][2][16][T], G0 [P][2][17] (self lanes), and
   const cf *selfW;     // [17]           W_M^k of self lane l: k = l*J (l <= 8), J/2 + (l-9)*J
+  cf Wself;            // plain form: W_M^(J/2) / W_32^9 = thread 0's twiddle base for its slots 9..15
 };
 
 // PCM sample formats at the batched boundary. Values mirror include/mi_upsampler.h.

@@ -394,27 +394,67 @@ struct FusedKernel {
   // overlap-discard (:566-569): compact samples n < Oc are dropped; the kept
   // ones go, still fp32 and phase-planar, to this workgroup's staging plane
   // (plane[i] = y_p[Oc + i]) with lane-contiguous 8-byte stores.
-  template <int R, bool kEvenOc, bool kNT = false>
-  static MI_DEVICE void plane_write(float *plane, int Oc, int q, const cf *v) {
-    MI_UNROLL
-    for (int u = 0; u < R; ++u) {
-      const int n = 2 * (q + u * (K / R));
-      const cf y = v[out_pos<R>(u)];
-      if constexpr (kEvenOc) {
-        if (n >= Oc) {
-#if !defined(MIUPS_HOST_EMU)
-          if constexpr (kNT) {
-            // planes that another kernel turns into frames: streaming stores, so that they do
-            // not push the phase spectra out of L2 (config 4 +5 %, config 5 +3 %)
-            // (two 4-byte streaming stores measured 2 % faster than one 8-byte one on configs 3 and 5)
-            __builtin_nontemporal_store(y.x, plane + (n - Oc));
-            __builtin_nontemporal_store(y.y, plane + (n - Oc) + 1);
-            continue;
-          }
+  // Even history length (every shipped geometry): output u of butterfly q is the complex word n2 = q + u*K/R of
+  // y_p and is kept iff n2 >= Oc/2; it goes to byte (n2 - Oc/2)*8 of the plane. The plane is addressed through a
+  // buffer descriptor of exactly its kept size and the offset is formed in UNSIGNED arithmetic: a discarded word's
+  // offset wraps past the end and the hardware drops the store. No compare, no exec-mask branch, no 64-bit address
+  // per store (the compare-and-branch form cost 12 instructions and a 5-cycle s_nop per store: the base pointer sat
+  // in VGPRs and was re-read with v_readfirstlane at every store).
+  struct PlaneDst {
+#if defined(MIUPS_HOST_EMU)
+    float *plane;
+    unsigned nkeep;
+#else
+    __amdgpu_buffer_rsrc_t rsrc;
 #endif
-          *reinterpret_cast<cf *>(plane + (n - Oc)) = y;
+    unsigned o2x8;  // (Oc/2) * 8
+    float *raw;     // odd history length: plain pointer path
+    int Oc;
+  };
+  static MI_DEVICE PlaneDst make_plane_dst(float *plane, int Oc, int nkeep) {
+    PlaneDst d;
+    d.raw = plane;
+    d.Oc = Oc;
+    d.o2x8 = (static_cast<unsigned>(Oc) >> 1) * 8u;
+#if defined(MIUPS_HOST_EMU)
+    d.plane = plane;
+    d.nkeep = static_cast<unsigned>(nkeep);
+#else
+    // the plane pointer is workgroup-uniform; tell the compiler (it keeps it in VGPRs otherwise)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(plane);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+    float *uniform = reinterpret_cast<float *>((static_cast<unsigned long long>(hi) << 32) | lo);
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform, 0, __builtin_amdgcn_readfirstlane(nkeep) * 4, 0x00020000);
+#endif
+    return d;
+  }
+  template <int R, bool kEvenOc, bool kNT = false>
+  static MI_DEVICE void plane_write(const PlaneDst &d, int q, const cf *v) {
+    if constexpr (kEvenOc) {
+      MI_UNROLL
+      for (int u = 0; u < R; ++u) {
+        const unsigned off = (static_cast<unsigned>(q) + static_cast<unsigned>(u) * (K / R)) * 8u - d.o2x8;
+        const cf y = v[out_pos<R>(u)];
+#if defined(MIUPS_HOST_EMU)
+        if (off < d.nkeep * 4u) {  // what the buffer range check does
+          *reinterpret_cast<cf *>(reinterpret_cast<char *>(d.plane) + off) = y;
         }
-      } else {
+#else
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 bits = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
+        // kNT: planes that another kernel turns into frames are stored with the streaming policy (aux 2 = nt), so that
+        // they do not push the phase spectra out of L2 (config 4 +5 %, config 5 +3 %)
+        __builtin_amdgcn_raw_buffer_store_b64(bits, d.rsrc, static_cast<int>(off), 0, kNT ? 2 : 0);
+#endif
+      }
+    } else {
+      float *plane = d.raw;
+      const int Oc = d.Oc;
+      MI_UNROLL
+      for (int u = 0; u < R; ++u) {
+        const int n = 2 * (q + u * (K / R));
+        const cf y = v[out_pos<R>(u)];
         if (n >= Oc) {
           plane[n - Oc] = y.x;
         }
@@ -561,7 +601,8 @@ struct FusedKernel {
   }
   // last pass: stride K/R, natural-order results -> staging plane
   template <bool kEvenOc, bool kNT = false>
-  static MI_DEVICE void inv_last(float *plane, int Oc, const cf *lds, const cf *tw, int tid) {
+  static MI_DEVICE void inv_last(float *plane_, int Oc, int nkeep, const cf *lds, const cf *tw, int tid) {
+    const PlaneDst plane = make_plane_dst(plane_, Oc, nkeep);
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
       MI_UNROLL
@@ -571,7 +612,7 @@ struct FusedKernel {
         lds_get<R0, S0>(lds, Bfly<R0, S0>(q), v);
         apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
         dftR<+1, R0>(v);
-        plane_write<R0, kEvenOc, kNT>(plane, Oc, q, v);
+        plane_write<R0, kEvenOc, kNT>(plane, q, v);
         if ((i & 3) == 3) {
           MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
         }
@@ -582,64 +623,88 @@ struct FusedKernel {
       lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
       apply_twiddles<+1, 16>(A, w0);
       dft16<+1>(A);
-      plane_write<16, kEvenOc, kNT>(plane, Oc, tid, A);
+      plane_write<16, kEvenOc, kNT>(plane, tid, A);
       MI_SCHED_FENCE();
       apply_twiddles<+1, 16>(B, cmul(w0, w32(1)));
       dft16<+1>(B);
-      plane_write<16, kEvenOc, kNT>(plane, Oc, tid + T, B);
+      plane_write<16, kEvenOc, kNT>(plane, tid + T, B);
     }
   }
 
   // ================= spectral stage ==========================================
-  // kSelf = thread 0 (self-mirrored sets). On entry Xa/Xb hold the split
-  // spectrum, on exit A/B hold the inputs of the first inverse pass in natural
-  // order (element t of the thread's two blocks).
-  template <bool kSelf>
-  static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wb, const f4 *MI_RESTRICT gt,
+  // A thread's sixteen mirror pairs: pair t = bins k = a + t*J and K - k = (J - a) + (15 - t)*J, with the untangle
+  // twiddle W_M^k = Wa * W_32^t. On entry Xa/Xb hold the split spectrum, on exit A/B hold the inputs of the first
+  // inverse pass in natural order (element t of the thread's two blocks).
+  //
+  // Thread 0 owns the two self-mirrored sets S_0 and S_{J/2}: 9 + 8 pairs INSIDE each set. It runs the same sixteen
+  // slots as every other thread -- slots 0..8 = the pairs of S_0 (its Wa is 1), slots 9..15 = the first seven pairs of
+  // S_{J/2} (twiddle base Wself = W_M^(J/2) / W_32^9 instead of Wa, so that Wself * W_32^s is the right twiddle; the
+  // host stores lane 0's spectra in column 0 of the same table) -- plus ONE extra pair and a register permutation under
+  // `tid == 0`. (A separate code path for thread 0 made wave 0 execute both paths at every phase: twice the spectral
+  // stage on the critical path of every barrier, half of the whole workgroup at K <= 4096.)
+  static MI_DEVICE cf slot_twiddle(int t, cf Wa, cf Wa2) { return cmul(t < 9 ? Wa : Wa2, w32(t)); }
+
+  static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wa2, cf Wb, const f4 *MI_RESTRICT gt,
                                      const f4 *MI_RESTRICT g0, cf *A, cf *B) {
-    if constexpr (!kSelf) {
-      // pair t: k = a + t*J  <->  K-k = (J-a) + (15-t)*J
-      const f4 *pg = gt + tid;
+    // pair t: k = a + t*J  <->  K-k = (J-a) + (15-t)*J
+    const f4 *pg = gt + tid;
+    MI_UNROLL
+    for (int t = 0; t < 16; ++t) {
+      pair_phase(Xa[t], Xb[t], slot_twiddle(t, Wa, Wa2), pg[t * T], A[t], B[15 - t]);
+    }
+    if (tid == 0) {
+      // slot s <= 8: zk is A[s] already, zkm belongs at A[16-s] (s = 1..7; DC and the self-mirrored bin have none);
+      // slot s >= 9 (pair s-9 of S_{J/2}): zk belongs at B[s-9], zkm at B[24-s]; the eighth pair is the extra one
+      cf ez, em;
+      pair_phase(Xa[16], Xb[16], cmul(Wb, w32(7)), g0[16], ez, em);
+      cf keep[7];
       MI_UNROLL
-      for (int t = 0; t < 16; ++t) {
-        pair_phase(Xa[t], Xb[t], cmul(Wa, w32(t)), pg[t * T], A[t], B[15 - t]);
+      for (int j = 0; j < 7; ++j) {
+        keep[j] = B[j];  // zkm of slots 15..9
       }
-    } else {
-      // set S_0: k = t*J <-> (16-t)*J, t = 0..8 (t = 0 pairs DC with Nyquist
-      // through gc = conj Gs[K]; t = 8 is its own mirror)
       MI_UNROLL
-      for (int t = 0; t <= 8; ++t) {
-        cf zk, zkm;
-        pair_phase(Xa[t], Xb[t], w32(t), g0[t], zk, zkm);
-        A[t] = zk;
-        if (t >= 1 && t <= 7) {
-          A[16 - t] = zkm;
-        }
+      for (int i = 9; i < 16; ++i) {
+        const cf zk = A[i];
+        A[i] = B[i - 1];  // zkm of slot 16-i
+        B[i - 9] = zk;
       }
-      // set S_{J/2}: k = J/2 + t*J <-> J/2 + (15-t)*J, t = 0..7
       MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        pair_phase(Xa[9 + t], Xb[9 + t], cmul(Wb, w32(t)), g0[9 + t], B[t], B[15 - t]);
+      for (int j = 9; j < 16; ++j) {
+        B[j] = keep[j - 9];  // zkm of pair t' = 15-j of S_{J/2} (slot 9+t') sat in B[15 - (9 + t')] = B[j - 9]
       }
+      B[7] = ez;
+      B[8] = em;
     }
   }
 
-  template <bool kSelf>
-  static MI_DEVICE void split_spectrum(const cf *A, const cf *B, cf Wa, cf Wb, cf *Xa, cf *Xb) {
-    if constexpr (!kSelf) {
+  static MI_DEVICE void split_spectrum(int tid, cf *A, cf *B, cf Wa, cf Wa2, cf Wb, cf *Xa, cf *Xb) {
+    Xa[16] = Xb[16] = mk(0.0f, 0.0f);
+    if (tid == 0) {
+      // lane 0: arrange its two sets as the sixteen (u, mirror) slots of the generic loop; the 17th pair on the side
+      pair_split(B[out_pos<16>(7)], B[out_pos<16>(8)], cmul(Wb, w32(7)), Xa[16], Xb[16]);
+      cf a0[16], b0[16];
       MI_UNROLL
       for (int t = 0; t < 16; ++t) {
-        pair_split(A[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wa, w32(t)), Xa[t], Xb[t]);
-      }
-    } else {
-      MI_UNROLL
-      for (int t = 0; t <= 8; ++t) {
-        pair_split(A[out_pos<16>(t)], A[out_pos<16>((16 - t) & 15)], w32(t), Xa[t], Xb[t]);
+        a0[t] = A[out_pos<16>(t)];
+        b0[t] = B[out_pos<16>(t)];
       }
       MI_UNROLL
-      for (int t = 0; t < 8; ++t) {
-        pair_split(B[out_pos<16>(t)], B[out_pos<16>(15 - t)], cmul(Wb, w32(t)), Xa[9 + t], Xb[9 + t]);
+      for (int s = 9; s < 16; ++s) {
+        A[out_pos<16>(s)] = b0[s - 9];           // u of slot s: element s-9 of S_{J/2}
       }
+      MI_UNROLL
+      for (int j = 0; j < 7; ++j) {
+        B[out_pos<16>(j)] = b0[j + 9];           // mirror of slot 15-j (>= 9): element 15-(15-j-9) = j+9 of S_{J/2}
+      }
+      MI_UNROLL
+      for (int j = 7; j < 15; ++j) {
+        B[out_pos<16>(j)] = a0[j + 1];           // mirror of slot 15-j (1..8): element 16-(15-j) of S_0
+      }
+      B[out_pos<16>(15)] = a0[0];                // slot 0 pairs DC with itself (Nyquist rides in gc)
+    }
+    MI_UNROLL
+    for (int t = 0; t < 16; ++t) {
+      pair_split(A[out_pos<16>(t)], B[out_pos<16>(15 - t)], slot_twiddle(t, Wa, Wa2), Xa[t], Xb[t]);
     }
   }
 
@@ -1075,11 +1140,8 @@ struct FusedKernel {
     cf Xa[17], Xb[17];
     const cf Wa = ft.WmT[tid];
     const cf Wb = ft.Wb;
-    if (tid == 0) {
-      split_spectrum<true>(A, B, Wa, Wb, Xa, Xb);
-    } else {
-      split_spectrum<false>(A, B, Wa, Wb, Xa, Xb);
-    }
+    const cf Wa2 = tid == 0 ? ft.Wself : Wa;
+    split_spectrum(tid, A, B, Wa, Wa2, Wb, Xa, Xb);
     MI_STAMP(sb + 8);
 
     // --------------------------- per output phase ------------------------
@@ -1095,11 +1157,7 @@ struct FusedKernel {
       float *plane = scr_c + static_cast<long long>(p) * g.Bc;
       int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
       MI_OPAQUE_VGPR(tl);
-      if (tid == 0) {
-        phase_inputs<true>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
-      } else {
-        phase_inputs<false>(tl, Xa, Xb, Wa, Wb, gt, g0, A, B);
-      }
+      phase_inputs(tl, Xa, Xb, Wa, Wa2, Wb, gt, g0, A, B);
       const int sp = sb + 9 + 10 * (pi & 3);
       (void)sp;
       MI_STAMP(sp + 0);
@@ -1127,14 +1185,14 @@ struct FusedKernel {
       MI_OPAQUE_VGPR(tl);
       if (evenOc) {
 #if defined(MIUPS_EXP_NT_PLANES_ALWAYS)  // experiment switch (profiles/): streaming plane stores with the in-kernel epilogue too
-        inv_last<true, true>(plane, b.Oc, lds, ft.tw, tl);
+        inv_last<true, true>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
 #elif defined(MIUPS_EXP_NO_NT_PLANES)  // experiment switch (profiles/): cached plane stores for the interleave kernels too
-        inv_last<true, false>(plane, b.Oc, lds, ft.tw, tl);
+        inv_last<true, false>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
 #else
-        inv_last<true, EXT>(plane, b.Oc, lds, ft.tw, tl);
+        inv_last<true, EXT>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
 #endif
       } else {
-        inv_last<false>(plane, b.Oc, lds, ft.tw, tl);
+        inv_last<false>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
       }
       MI_STAMP(sp + 7);
       MI_SYNC();  // every read of this phase done before the next phase's first pass writes
@@ -1285,7 +1343,7 @@ struct FusedKernel {
         MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
-      inv_last<true, true>(half, g.Oc >> 1, lds, ft.tw, tl);
+      inv_last<true, true>(half, g.Oc >> 1, g.Bc >> 1, lds, ft.tw, tl);
       MI_STAMP(sp + 7);
       MI_SYNC();
       MI_STAMP(sp + 8);

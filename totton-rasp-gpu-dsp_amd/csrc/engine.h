@@ -34,9 +34,9 @@ struct TableSet {
   cf *Gs = nullptr, *Gc = nullptr, *Wm = nullptr, *tw = nullptr, *WmT = nullptr, *selfW = nullptr;
   int *blockB = nullptr;
   f4 *GT = nullptr, *G0 = nullptr;
-  cf wb{1.0f, 0.0f};
+  cf wb{1.0f, 0.0f}, wself{1.0f, 0.0f};
   std::size_t count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // elements per array (pool reuse needs the same shape)
-  FusedTables fused() const { return FusedTables{tw, WmT, blockB, GT, G0, wb, selfW}; }
+  FusedTables fused() const { return FusedTables{tw, WmT, blockB, GT, G0, wb, selfW, wself}; }
   ~TableSet();
 };
 struct TablePool;  // retired sets of one filter, free for reuse

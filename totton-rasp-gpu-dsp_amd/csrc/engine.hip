@@ -414,6 +414,7 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
     return false;  // `set` is freed here; cur_ is unchanged
   }
   set->wb = t.Wb;
+  set->wself = t.Wself;
   std::lock_guard<std::mutex> lock(mu_);
   if (!cur_) {
     geo_ = t.geo;

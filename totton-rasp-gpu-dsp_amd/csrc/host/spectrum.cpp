@@ -67,6 +67,16 @@ void BuildFusedLayout(FilterTables *t) {
     for (int s = 0; s < 8; ++s) {
       t->G0[static_cast<std::size_t>(p) * 17 + 9 + s] = pair(p, J / 2 + s * J);
     }
+    // thread 0 runs the generic sixteen slots on column 0 of GT (its 17th pair stays in G0[16])
+    for (int s = 0; s < 16; ++s) {
+      t->GT[(static_cast<std::size_t>(p) * 16 + s) * T + 0] = t->G0[static_cast<std::size_t>(p) * 17 + s];
+    }
+  }
+  {
+    // twiddle base of thread 0's slots 9..15: W_M^(J/2) * W_32^(s-9) = Wself * W_32^s, M = 32 J
+    const double pi = 3.14159265358979323846264338327950288;
+    const double a = 2.0 * pi * 17.0 / 64.0;
+    t->Wself = cf{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
   }
   t->hasFused = true;
 }

@@ -38,6 +38,7 @@ struct FilterTables {
   std::vector<f4> GT;       // [P][16][T]
   std::vector<f4> G0;       // [P][17]
   cf Wb{1.0f, 0.0f};
+  cf Wself{1.0f, 0.0f};     // plain layout: thread 0's twiddle base for its slots 9..15
   std::vector<cf> selfW;    // split layout only
 };
 
