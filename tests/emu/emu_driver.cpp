@@ -48,12 +48,24 @@ void barrier() {
 }
 void *dyn_shared() { return g_shared.data(); }
 
+// cross-lane exchange of the narrow kernel (v_permlane32_swap on the GPU): every thread of the block calls it
+static std::vector<float> g_xch;
+float xchg_xor(float v, unsigned mask) {
+  const unsigned me = t_threadIdx.x;
+  g_xch[me] = v;
+  barrier();
+  const float r = g_xch[me ^ mask];
+  barrier();
+  return r;
+}
+
 // run f() once per (block, thread); with barriers every thread of a block is a
 // real OS thread, otherwise threads run back to back.
 void launch(unsigned grid, unsigned block, size_t shmem, bool barriers, const std::function<void()> &f) {
   g_gridDim.x = grid;
   g_blockDim.x = block;
   g_shared.assign(shmem, 0);
+  g_xch.assign(block, 0.0f);
   g_use_bar = barriers && block > 1;
   for (unsigned b = 0; b < grid; ++b) {
     if (!g_use_bar) {
@@ -121,8 +133,19 @@ cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
 
 template <int LOG2K>
 void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
-  using Cfg = FusedCfg<LOG2K>;
   const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr, t.Wself};
+  if constexpr (LOG2K >= 10) {
+    if (t.fusedNarrow) {  // one butterfly per thread (experiment form, EMU_NARROW)
+      using CfgN = FusedCfg<LOG2K, 1>;
+      if (io.ext_epilogue) {
+        miups_emu::launch(items, CfgN::T, CfgN::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 1>(g, io, ft); });
+      } else {
+        miups_emu::launch(items, CfgN::T, CfgN::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 1>(g, io, ft); });
+      }
+      return;
+    }
+  }
+  using Cfg = FusedCfg<LOG2K>;
   if (io.ext_epilogue) {
     miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true>(g, io, ft); });
   } else {
@@ -179,6 +202,9 @@ int main(int argc, char **argv) {
   int flags = std::atoi(argv[2]);
   if (std::getenv("EMU_SPLIT")) {  // tests: the split layout at sizes the emulation can run
     flags |= kLoadInternalForceSplit;
+  }
+  if (std::getenv("EMU_NARROW")) {  // tests: one butterfly per thread (experiment form) where it exists
+    flags |= kLoadInternalNarrow;
   }
   const int streams = std::atoi(argv[3]), channels = std::atoi(argv[4]);
   const int inFmt = std::atoi(argv[5]), outFmt = std::atoi(argv[6]);

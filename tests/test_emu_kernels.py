@@ -52,6 +52,34 @@ CASES = [
     (4096, 1025, 8, "fused", 1, 12, 2, 1),  # 12 channels
     (8192, 2049, 1, "fused", 1, 1, 1, 2),  # K = 4096 (radices 16,16,16)
 ]
+NARROW_CASES = [
+    (2048, 600, 1, 1, 2, 2, 2),   # K = 1024 = 4*16*16: one wave
+    (8192, 2001, 2, 2, 2, 3, 1),  # K = 2048 = 8*16*16, stereo
+    (4096, 1024, 1, 1, 1, 2, 2),  # K = 2048, odd history length (taps - 1 = 1023)
+    (8192, 2049, 1, 1, 1, 1, 2),  # K = 4096 = 16^3
+    (16384, 4097, 1, 1, 2, 1, 2), # K = 8192 = 2*16^3
+]
+
+
+@pytest.mark.parametrize("fft,taps,L,streams,channels,blocks,calls", NARROW_CASES)
+def test_emulated_narrow_form(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, streams, channels, blocks, calls):
+    """The one-butterfly-per-thread experiment form (K >= 1024: each mirror pair's two sets in lanes l and l ^ 32, traded
+    through the lane exchange; kernel_fused.h "narrow form") against fp64 truth."""
+    monkeypatch.setenv("EMU_NARROW", "1")
+    rng = np.random.default_rng(fft + L)
+    h = rng.standard_normal(taps).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    x = rng.standard_normal((calls, streams, blocks * nin, channels)).astype(np.float32)
+    out = run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, calls, "fused")
+    y = np.frombuffer(out, np.float32).reshape(calls, streams, blocks * block, channels)
+    for s_ in range(streams):
+        for c in range(channels):
+            xs = np.concatenate([x[k, s_, :, c] for k in range(calls)])
+            truth = O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1)
+            got = np.concatenate([y[k, s_, :, c] for k in range(calls)])
+            assert np.abs(got - truth).max() <= 1e-5 * np.abs(truth).max()
 
 
 @pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", CASES)

@@ -23,6 +23,7 @@ extern Dim3 g_blockDim;
 extern Dim3 g_gridDim;
 void barrier();
 void *dyn_shared();
+float xchg_xor(float v, unsigned mask);  // value of thread (threadIdx.x ^ mask); called by every thread of the block
 }  // namespace miups_emu
 #define MI_DEVICE inline
 #define MI_HD inline
@@ -126,6 +127,23 @@ MI_DEVICE v2 vmulc(v2 a, v2 w) { return v2crossc(a, w, a * v2xx(w)); }
 MI_DEVICE v2 vmulj(v2 a) { return v2swap(a) * v2mk(-1.0f, 1.0f); }
 MI_DEVICE v2 vmulnj(v2 a) { return v2swap(a) * v2mk(1.0f, -1.0f); }
 MI_DEVICE v2 vconj(v2 a) { return a * v2mk(1.0f, -1.0f); }
+
+// The value the partner lane (lane ^ 32 of the same wave) holds in `a`. Two v_permlane32_swap_b32 move both dwords
+// both ways at once: `swap x, y` exchanges x's upper half-wave with y's lower one, so after `swap x, y; swap y, x`
+// y holds the partner's x and x the partner's y -- no copies, no selects, no LDS. Spelled in asm because the chained
+// form of __builtin_amdgcn_permlane32_swap miscompiles on ROCm 7.2 (both results read from one register: checked on the
+// GPU with scripts/ubench/permlane_check.hip, which also validates this sequence); the s_nop are the VALU-write ->
+// v_permlane read wait states.
+MI_DEVICE cf xchg32(cf a) {
+#if defined(MIUPS_HOST_EMU)
+  return mk(::miups_emu::xchg_xor(a.x, 32u), ::miups_emu::xchg_xor(a.y, 32u));
+#else
+  float x = a.x, y = a.y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\ts_nop 1"
+               : "+v"(x), "+v"(y));
+  return mk(y, x);
+#endif
+}
 
 MI_DEVICE cf cadd(cf a, cf b) { return C(V(a) + V(b)); }
 MI_DEVICE cf csub(cf a, cf b) { return C(V(a) - V(b)); }

@@ -67,7 +67,7 @@ __device__ unsigned long long mi_stamps[32][8][192];
 #endif
 #define MI_STAMP(id)                                                                                   \
   do {                                                                                                 \
-    if ((MI_TID_X & 63) == 0 && MI_BID_X >= MIUPS_STAMP_BASE && MI_BID_X < MIUPS_STAMP_BASE + 32) {   \
+    if ((MI_TID_X & 63) == 0 && MI_TID_X < 512 && MI_BID_X >= MIUPS_STAMP_BASE && MI_BID_X < MIUPS_STAMP_BASE + 32) { \
       mi_stamps[MI_BID_X - MIUPS_STAMP_BASE][MI_TID_X >> 6][(id)] = __builtin_amdgcn_s_memtime();     \
     }                                                                                                  \
   } while (0)
@@ -250,11 +250,20 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
   return b;
 }
 
-template <int LOG2K>
+// W = radix-16 butterflies per thread and pass.
+//   W = 2 ("wide"):   T = K/32 threads with up to 256 registers: two waves per SIMD. A thread owns both sets of its
+//                     mirror pairs. Used for K < 1024 and by the split form.
+//   W = 1 ("narrow"): T = K/16 threads with at most 128 registers: FOUR waves per SIMD (K = 16384: one 1024-thread
+//                     workgroup; K = 4096: four 256-thread workgroups per CU). Half the live state per thread, and a
+//                     SIMD with four waves issues a VALU instruction every 1.72 cycles instead of every 2.47 with two
+//                     (profiles/r02_a_ubench_valu_lds_rates.txt) -- the passes are VALU-issue bound. The two sets of a
+//                     mirror pair live in lanes l and l ^ 32 of one wave and trade eight values through
+//                     v_permlane32_swap (xchg32) on either side of the spectral product.
+template <int LOG2K, int W = 2>
 struct FusedCfg {
   static constexpr int K = 1 << LOG2K;
   static constexpr int J = K / 16;       // sixteen-word LDS blocks / radix-16 butterflies per pass
-  static constexpr int T = K / 32;       // threads per workgroup
+  static constexpr int T = K / (16 * W); // threads per workgroup
   static constexpr int R0 = 1 << (LOG2K % 4);
   static constexpr int LOG2R0 = LOG2K % 4;
   static constexpr int N16 = LOG2K / 4;  // radix-16 passes
@@ -263,6 +272,7 @@ struct FusedCfg {
   static constexpr int LDS_BYTES = K * 8;
   static constexpr int LDS_BYTES_SPLIT = K * 8 + 64 * 8;  // + FusedKernel::kXchWords
   static_assert(LOG2K >= 5 && LOG2K <= 14, "fused kernel covers K = 32 .. 16384");
+  static_assert(W == 2 || (W == 1 && LOG2K >= 10), "the narrow form needs whole waves: K >= 1024");
   // LDS block of the thread's first set in the pairing passes: the tau-th block
   // whose low digit is < RL/2 (exactly the sets S_a with a < J/2)
   static MI_HD constexpr int block_a(int tau) { return (tau / (RL / 2)) * RL + (tau % (RL / 2)); }
@@ -309,9 +319,9 @@ struct Bfly {
   }
 };
 
-template <int LOG2K>
+template <int LOG2K, int W = 2>
 struct FusedKernel {
-  using Cfg = FusedCfg<LOG2K>;
+  using Cfg = FusedCfg<LOG2K, W>;
   static constexpr int K = Cfg::K, J = Cfg::J, T = Cfg::T, R0 = Cfg::R0, N16 = Cfg::N16;
   static constexpr int LOG2R0 = Cfg::LOG2R0;
   static constexpr int S0 = K / R0;  // stride of the radix-R0 pass (= 16^N16)
@@ -469,23 +479,30 @@ struct FusedKernel {
   // pass 0 from HBM: y_u = DFT_R(x)_u * W_K^(u*q), written to q + u*K/R
   template <int FMT, bool kHist, int MODE, int SP = 0>
   static MI_DEVICE void fwd_first(const BlockIo &b, cf *lds, const cf *tw, int tid) {
-    // W_K^(tid + i*T) = W_K^tid * W_32^i : one table load for all butterflies
+    // W_K^(tid + i*T) = W_K^tid * W_(16W)^i : one table load for all butterflies
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
       // every input load of the thread is issued before the first butterfly, so the
       // HBM round trip is paid once, not once per butterfly
-      cf raw[32 / R0][R0];
+      constexpr int NB = 16 * W / R0;
+      cf raw[NB][R0];
       MI_UNROLL
-      for (int i = 0; i < 32 / R0; ++i) {
+      for (int i = 0; i < NB; ++i) {
         global_read<FMT, R0, kHist, MODE, SP>(b, tid + i * T, raw[i]);
       }
       MI_UNROLL
-      for (int i = 0; i < 32 / R0; ++i) {
+      for (int i = 0; i < NB; ++i) {
         const int q = tid + i * T;
         dftR<-1, R0>(raw[i]);
-        apply_twiddles_out<-1, R0>(raw[i], i == 0 ? w0 : cmul(w0, w32(i)));
+        apply_twiddles_out<-1, R0>(raw[i], i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
         lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), raw[i]);
       }
+    } else if constexpr (W == 1) {
+      cf A[16];
+      global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
+      dft16<-1>(A);
+      apply_twiddles_out<-1, 16>(A, w0);
+      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
     } else {
       cf A[16], B[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
@@ -522,6 +539,15 @@ struct FusedKernel {
   template <int S>
   static MI_DEVICE void fwd_mid(cf *lds, const cf *tw, int tid) {
     constexpr int LOG2L = (S == 16) ? 8 : 12;
+    if constexpr (W == 1) {
+      const Bfly<16, S> bf(tid);
+      cf V[16];
+      lds_get<16, S>(lds, bf, V);
+      dft16<-1>(V);
+      apply_twiddles_out<-1, 16>(V, load_tw<LOG2L>(tw, tid & (S - 1)));
+      lds_put_dft<16, S>(lds, bf, V);
+      return;
+    }
     const int qA = tid, qB = tid + T;
     const cf wA = load_tw<LOG2L>(tw, qA & (S - 1));
     const cf wB = (T % S == 0) ? wA : load_tw<LOG2L>(tw, qB & (S - 1));
@@ -572,6 +598,15 @@ struct FusedKernel {
   template <int S>
   static MI_DEVICE void inv_mid(cf *lds, const cf *tw, int tid) {
     constexpr int LOG2L = (S == 16) ? 8 : 12;
+    if constexpr (W == 1) {
+      const Bfly<16, S> bf(tid);
+      cf V[16];
+      lds_get<16, S>(lds, bf, V);
+      apply_twiddles<+1, 16>(V, load_tw<LOG2L>(tw, tid & (S - 1)));
+      dft16<+1>(V);
+      lds_put_dft<16, S>(lds, bf, V);
+      return;
+    }
     const int qA = tid, qB = tid + T;
     const cf wA = load_tw<LOG2L>(tw, qA & (S - 1));
     const cf wB = (T % S == 0) ? wA : load_tw<LOG2L>(tw, qB & (S - 1));
@@ -606,17 +641,23 @@ struct FusedKernel {
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
       MI_UNROLL
-      for (int i = 0; i < 32 / R0; ++i) {
+      for (int i = 0; i < 16 * W / R0; ++i) {
         const int q = tid + i * T;
         cf v[R0];
         lds_get<R0, S0>(lds, Bfly<R0, S0>(q), v);
-        apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i)));
+        apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
         dftR<+1, R0>(v);
         plane_write<R0, kEvenOc, kNT>(plane, q, v);
         if ((i & 3) == 3) {
           MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
         }
       }
+    } else if constexpr (W == 1) {
+      cf A[16];
+      lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      apply_twiddles<+1, 16>(A, w0);
+      dft16<+1>(A);
+      plane_write<16, kEvenOc, kNT>(plane, tid, A);
     } else {
       cf A[16], B[16];
       lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
@@ -705,6 +746,70 @@ struct FusedKernel {
     MI_UNROLL
     for (int t = 0; t < 16; ++t) {
       pair_split(A[out_pos<16>(t)], B[out_pos<16>(15 - t)], slot_twiddle(t, Wa, Wa2), Xa[t], Xb[t]);
+    }
+  }
+
+  // ================= spectral stage, narrow form (W = 1) =====================
+  // Lane l of a wave holds the sixteen bins own[t] = Z[k0 + t*J] of ONE set S_k0; its partner lane l ^ 32 holds the
+  // mirror set S_(J-k0). Mirror of own[j] is the partner's own[15-j], so each lane takes the eight pairs of its own
+  // bins j = 0..7 (the partner takes the other eight): it sends own[15..8], receives the partner's, untangles /
+  // multiplies / re-tangles its eight pairs with twiddle W_M^(k0 + j*J) = Wl * W_32^j, keeps zk (its own bin j) and
+  // sends zkm (the partner's bin 15-j) back. Both lanes run the same instructions on the same register names.
+  // The two self-mirrored sets sit in lanes 0 (S_0: pairs (t, 16-t), nine of them) and 32 (S_{J/2}: pairs
+  // (t, 15-t)) of wave 0; they take part in the exchanges like everyone and then replace what they received by a
+  // permutation of their own values (lane 0 also computes its ninth pair) under `tid == 0` / `tid == 32`.
+  static MI_DEVICE void split_spectrum_n(int tid, const cf *A, cf Wl, cf *Xa, cf *Xb) {
+    cf recv[8];
+    MI_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      recv[j] = xchg32(A[out_pos<16>(15 - j)]);
+    }
+    Xa[8] = Xb[8] = mk(0.0f, 0.0f);
+    if (tid == 0) {
+      // S_0: the mirror of own[j] is own[(16-j) & 15]; own[8] is its own mirror (ninth pair)
+      recv[0] = A[out_pos<16>(0)];
+      MI_UNROLL
+      for (int j = 1; j < 8; ++j) {
+        recv[j] = A[out_pos<16>(16 - j)];
+      }
+      pair_split(A[out_pos<16>(8)], A[out_pos<16>(8)], w32(8), Xa[8], Xb[8]);
+    } else if (tid == 32) {
+      MI_UNROLL
+      for (int j = 0; j < 8; ++j) {
+        recv[j] = A[out_pos<16>(15 - j)];  // S_{J/2}: the mirror of own[j] is own[15-j]
+      }
+    }
+    MI_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      pair_split(A[out_pos<16>(j)], recv[j], cmul(Wl, w32(j)), Xa[j], Xb[j]);
+    }
+  }
+  // gt: this phase's [8][T] table, g0: this phase's entry of lane 0's ninth pair; V: inputs of the first inverse
+  // pass in natural order
+  static MI_DEVICE void phase_inputs_n(int tid, const cf *Xa, const cf *Xb, cf Wl, const f4 *MI_RESTRICT gt,
+                                       const f4 *MI_RESTRICT g0, cf *V) {
+    const f4 *pg = gt + tid;
+    cf zkm[8];
+    MI_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      pair_phase(Xa[j], Xb[j], cmul(Wl, w32(j)), pg[j * T], V[j], zkm[j]);
+    }
+    MI_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      V[15 - j] = xchg32(zkm[j]);
+    }
+    if (tid == 0) {
+      MI_UNROLL
+      for (int j = 1; j < 8; ++j) {
+        V[16 - j] = zkm[j];  // the mirror bins are lane 0's own (zkm[0] pairs DC with Nyquist: no bin of its own)
+      }
+      cf unused;
+      pair_phase(Xa[8], Xb[8], w32(8), g0[0], V[8], unused);
+    } else if (tid == 32) {
+      MI_UNROLL
+      for (int j = 0; j < 8; ++j) {
+        V[15 - j] = zkm[j];
+      }
     }
   }
 
@@ -837,7 +942,7 @@ struct FusedKernel {
     const int units = g.Bc * qn;
     // kDepth units per step so that kDepth*VPT plane loads are in flight per lane
     // (the planes come back from L2 / Infinity Cache, ~1-2 us round trip)
-    constexpr int kDepth = VPT >= 16 ? 4 : 8;
+    constexpr int kDepth = (VPT >= 16 ? 4 : 8) / (W == 1 ? 2 : 1);  // the narrow form has half the registers, twice the threads
     for (int base = tid; base < units; base += T * kDepth) {
       float v[kDepth][VPT];
       MI_UNROLL
@@ -868,6 +973,57 @@ struct FusedKernel {
           for (int e = 0; e < VPT; e += 4) {
             const int pp = e / cg, cc = e - pp * cg;
             char *dst = out_blk + ((frame0 + pp) * io.channels + cc) * 4 - 4 * e;
+            if constexpr (FMT == kF32) {
+              *reinterpret_cast<f4 *>(dst + 4 * e) = f4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
+            } else {
+              struct alignas(16) I4 {
+                int32_t a, b, c, d;
+              };
+              I4 w;
+              w.a = static_cast<int32_t>(pcm_clamp(v[d][e], 0.9999999f) * 2147483648.0f);
+              w.b = static_cast<int32_t>(pcm_clamp(v[d][e + 1], 0.9999999f) * 2147483648.0f);
+              w.c = static_cast<int32_t>(pcm_clamp(v[d][e + 2], 0.9999999f) * 2147483648.0f);
+              w.d = static_cast<int32_t>(pcm_clamp(v[d][e + 3], 0.9999999f) * 2147483648.0f);
+              *reinterpret_cast<I4 *>(dst + 4 * e) = w;
+            }
+          }
+        }
+      }
+    }
+  }
+  // The same for the usual case pg == P (a unit = one i = all R = cg*P values of P consecutive frames = R consecutive
+  // output samples): every plane base is wave-uniform (scalar registers), the only per-lane address words are the 32-bit
+  // byte offsets 4*i (loads, shared by all R planes) and 4*R*i (stores) -- the epilogue's address arithmetic was most
+  // of its instruction stream (profiles/r02_d_*: it ran 1.6x faster with twice the waves, i.e. issue-bound).
+  template <int FMT, int R>
+  static MI_DEVICE void epilogue_rows(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
+    const unsigned Bc = static_cast<unsigned>(g.Bc), cg = static_cast<unsigned>(io.cg), P = static_cast<unsigned>(g.P);
+    constexpr int kDepth = (R >= 16 ? 4 : 8) / (W == 1 ? 2 : 1);
+    const float *pl[R];  // value e of a unit = (phase e / cg, channel e % cg)
+    MI_UNROLL
+    for (int e = 0; e < R; ++e) {
+      const unsigned pp = static_cast<unsigned>(e) / cg, cc = static_cast<unsigned>(e) - pp * cg;
+      pl[e] = scr + static_cast<size_t>(cc * P + pp) * Bc;
+    }
+    for (unsigned base = static_cast<unsigned>(tid); base < Bc; base += T * kDepth) {
+      float v[kDepth][R];
+      MI_UNROLL
+      for (int d = 0; d < kDepth; ++d) {
+        const unsigned i = base + d * T;
+        if (i < Bc) {
+          MI_UNROLL
+          for (int e = 0; e < R; ++e) {
+            v[d][e] = pl[e][i];
+          }
+        }
+      }
+      MI_UNROLL
+      for (int d = 0; d < kDepth; ++d) {
+        const unsigned i = base + d * T;
+        if (i < Bc) {
+          char *dst = out_blk + static_cast<size_t>(i * static_cast<unsigned>(4 * R));
+          MI_UNROLL
+          for (int e = 0; e < R; e += 4) {
             if constexpr (FMT == kF32) {
               *reinterpret_cast<f4 *>(dst + 4 * e) = f4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
             } else {
@@ -968,7 +1124,7 @@ struct FusedKernel {
   // microseconds of latency: the epilogue is latency-bound unless this much is in flight).
   template <int FMT>
   static MI_DEVICE void epilogue_quad(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
-    constexpr int kUnits = 8;
+    constexpr int kUnits = W == 1 ? 4 : 8;  // (the narrow form has half the registers, twice the threads)
     const int P = g.P, cg = io.cg;
     const int lcg = __builtin_ctz(cg), lRq = lcg + __builtin_ctz(P) - 2;  // log2(R/4)
     const int units = (g.Bc >> 2) << lRq;
@@ -1074,6 +1230,18 @@ struct FusedKernel {
     const bool runs_ok = cg == io.channels || (cg % 4 == 0 && io.channels % 4 == 0);
     const bool vec = pow2 && io.out_vec_ok && runs_ok && cg <= 16 && vpt >= 4 &&
                      (io.out_fmt == kF32 || io.out_fmt == kS32);
+    if (vec && pg == g.P && cg == io.channels && static_cast<long long>(g.B) * cg * 4 < (1ll << 32)) {
+      if (io.out_fmt == kF32) {
+        if (vpt == 4) epilogue_rows<kF32, 4>(g, io, out_blk, scr, tid);
+        else if (vpt == 8) epilogue_rows<kF32, 8>(g, io, out_blk, scr, tid);
+        else epilogue_rows<kF32, 16>(g, io, out_blk, scr, tid);
+      } else {
+        if (vpt == 4) epilogue_rows<kS32, 4>(g, io, out_blk, scr, tid);
+        else if (vpt == 8) epilogue_rows<kS32, 8>(g, io, out_blk, scr, tid);
+        else epilogue_rows<kS32, 16>(g, io, out_blk, scr, tid);
+      }
+      return;
+    }
     if (vec) {
       if (io.out_fmt == kF32) {
         if (vpt == 4) epilogue_vec<kF32, 4>(g, io, out_blk, scr, tid);
@@ -1129,6 +1297,75 @@ struct FusedKernel {
       MI_SYNC();
       MI_STAMP(sb + 6);
     }
+    const bool evenOc = (b.Oc & 1) == 0;
+    // Workgroups that share an XCD run in near lockstep and would all pull the same
+    // spectrum lines out of the same L2 channels at the same moment (measured: 3.5x
+    // slower phase-spectrum loads). Each starts its phase loop at a different phase.
+    const int rot = (MI_BID_X >> 3) + cc;
+    if constexpr (W == 1) {
+      // ---- narrow form: one set per lane, mirror set in lane ^ 32 ----
+      const int blk = ft.blockB[tid];  // this lane's LDS block in the two stride-1 passes
+      cf V[16];
+      lds_get<16, 1>(lds, Bfly<16, 1>(blk), V);
+      dft16<-1>(V);
+      MI_STAMP(sb + 7);
+      cf Xa[9], Xb[9];
+      const cf Wl = ft.WmT[tid];
+      split_spectrum_n(tid, V, Wl, Xa, Xb);
+      MI_STAMP(sb + 8);
+      for (int pi = 0; pi < g.P; ++pi) {
+        const int p = (pi + rot) % g.P;
+        const f4 *gt = ft.GT + static_cast<long long>(p) * 8 * T;
+        const f4 *g0 = ft.G0 + p;
+        float *plane = scr_c + static_cast<long long>(p) * g.Bc;
+        int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
+        MI_OPAQUE_VGPR(tl);
+        phase_inputs_n(tl, Xa, Xb, Wl, gt, g0, V);
+        const int sp = sb + 9 + 10 * (pi & 3);
+        (void)sp;
+        MI_STAMP(sp + 0);
+        int bk = blk;
+        MI_OPAQUE_VGPR(bk);
+        dft16<+1>(V);
+        lds_put_dft<16, 1>(lds, Bfly<16, 1>(bk), V);
+        MI_STAMP(sp + 1);
+        MI_SYNC();
+        MI_STAMP(sp + 2);
+        if constexpr (kFirstMidStride >= 16) {
+          MI_OPAQUE_VGPR(tl);
+          inv_mid<16>(lds, ft.tw, tl);
+          MI_STAMP(sp + 3);
+          MI_SYNC();
+          MI_STAMP(sp + 4);
+        }
+        if constexpr (kFirstMidStride >= 256) {
+          MI_OPAQUE_VGPR(tl);
+          inv_mid<256>(lds, ft.tw, tl);
+          MI_STAMP(sp + 5);
+          MI_SYNC();
+          MI_STAMP(sp + 6);
+        }
+        MI_OPAQUE_VGPR(tl);
+        if (evenOc) {
+          inv_last<true, EXT>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+        } else {
+          inv_last<false>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+        }
+        MI_STAMP(sp + 7);
+        MI_SYNC();  // every read of this phase done before the next phase's first pass writes
+        MI_STAMP(sp + 8);
+      }
+    } else {
+      channel_block_wide<EXT>(g, b, scr_c, ft, lds, tid, sb, evenOc, rot);
+    }
+  }
+
+  // the wide form's second half: last forward pass in registers, split, phase loop
+  template <bool EXT>
+  static MI_DEVICE void channel_block_wide(const Geometry &g, const BlockIo &b, float *scr_c, const FusedTables &ft, cf *lds,
+                                           int tid, int sb, bool evenOc, int rot) {
+    (void)sb;
+    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
     cf A[16], B[16];
@@ -1145,11 +1382,6 @@ struct FusedKernel {
     MI_STAMP(sb + 8);
 
     // --------------------------- per output phase ------------------------
-    const bool evenOc = (b.Oc & 1) == 0;
-    // Workgroups that share an XCD run in near lockstep and would all pull the same
-    // spectrum lines out of the same L2 channels at the same moment (measured: 3.5x
-    // slower phase-spectrum loads). Each starts its phase loop at a different phase.
-    const int rot = (MI_BID_X >> 3) + cc;
     for (int pi = 0; pi < g.P; ++pi) {
       const int p = (pi + rot) % g.P;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
@@ -1398,15 +1630,15 @@ struct FusedKernel {
 
 // EXT = false: whole-frame groups, frames written by the kernel's own epilogue;
 // EXT = true: io.ext_epilogue, the kernel stops at the staging planes (see channel_block).
-// Launch bounds: at least two waves per SIMD, i.e. at most 256 registers per lane, for every size. (With "1" hipcc
-// parks 9-18 values of the K <= 8192 kernels in AGPRs instead of spilling them: 272 registers, ONE wave per SIMD, and a
-// lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5: profiles/r02_a_ubench_valu_lds_rates.txt.)
-template <int LOG2K, bool EXT>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 2) void fused_kernel(Geometry g,
-                                                                                                      IoDesc io,
-                                                                                                      FusedTables ft) {
+// Launch bounds: the wide form at least two waves per SIMD, i.e. at most 256 registers per lane, for every size (with
+// "1" hipcc parks 9-18 values of the K <= 8192 kernels in AGPRs instead of spilling them: 272 registers, ONE wave per
+// SIMD, and a lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5:
+// profiles/r02_a_ubench_valu_lds_rates.txt); the narrow form four waves per SIMD = at most 128 registers.
+template <int LOG2K, bool EXT, int W = 2>
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : 2)) void fused_kernel(
+    Geometry g, IoDesc io, FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K>::template run<false, EXT>(g, io, ft, lds);
+  FusedKernel<LOG2K, W>::template run<false, EXT>(g, io, ft, lds);
 }
 
 // Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see

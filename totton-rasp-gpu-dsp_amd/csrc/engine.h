@@ -58,6 +58,7 @@ class DeviceFilter {
   const Geometry &geometry() const { return geo_; }  // fixed by the filter file; an EQ change never alters it
   bool hasFused() const { return hasFused_; }
   bool fusedSplit() const { return fusedSplit_; }  // tables are laid out for fused_split_kernel
+  bool fusedNarrow() const { return fusedNarrow_; }  // ... for the one-butterfly-per-thread form
   // current tables; the caller keeps the pointer for as long as enqueued work may read them
   std::shared_ptr<const TableSet> tables() const;
   unsigned long long generation() const;  // bumped by every successful SetEq
@@ -73,7 +74,7 @@ class DeviceFilter {
   std::vector<float> taps_;
   int flags_ = 0;
   Geometry geo_{};
-  bool hasFused_ = false, fusedSplit_ = false;
+  bool hasFused_ = false, fusedSplit_ = false, fusedNarrow_ = false;
   mutable std::mutex mu_;
   std::shared_ptr<const TableSet> cur_;
   std::shared_ptr<TablePool> pool_;

@@ -141,27 +141,42 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
   return src;
 }
 
-template <int LOG2K, bool EXT>
+template <int LOG2K, bool EXT, int W>
 bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
                         std::string *error) {
-  using Cfg = FusedCfg<LOG2K>;
+  using Cfg = FusedCfg<LOG2K, W>;
   static bool attr_set[64] = {};
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));
   if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2K, EXT>),
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2K, EXT, W>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, ft);
+  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT, W>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, ft);
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
 }
 
+// narrow = the tables are in the narrow layout (K >= 1024): one butterfly per thread
 template <int LOG2K>
-bool LaunchFused(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
+bool LaunchFused(const Geometry &g, const IoDesc &io, const FusedTables &ft, bool narrow, unsigned items, hipStream_t st,
                  std::string *error) {
-  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true>(g, io, ft, items, st, error)
-                         : LaunchFusedVariant<LOG2K, false>(g, io, ft, items, st, error);
+  if constexpr (LOG2K >= 10) {
+#if !defined(MIUPS_NO_NARROW)
+    if (narrow) {
+      return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true, 1>(g, io, ft, items, st, error)
+                             : LaunchFusedVariant<LOG2K, false, 1>(g, io, ft, items, st, error);
+    }
+#endif
+  }
+  if (narrow) {
+    if (error) {
+      *error = "narrow tables without a narrow kernel";
+    }
+    return false;
+  }
+  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true, 2>(g, io, ft, items, st, error)
+                         : LaunchFusedVariant<LOG2K, false, 2>(g, io, ft, items, st, error);
 }
 
 template <int LOG2K>
@@ -180,7 +195,7 @@ bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const FusedTables &ft
   return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
 }
 
-bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, unsigned items,
+bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, bool narrow, unsigned items,
                    hipStream_t st, std::string *error) {
   if (split) {
     // block transform length K = 32768: two 16384-point transforms through the LDS
@@ -199,12 +214,12 @@ bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bo
 // MIUPS_ONLY_LOG2K=n (scripts/build_variant.sh): experiment builds instantiate one transform length only (seconds, not minutes)
 #if !defined(MIUPS_ONLY_LOG2K)
 #define MI_FUSED_CASE(n) \
-  case n: return LaunchFused<n>(g, io, f, items, st, error);
+  case n: return LaunchFused<n>(g, io, f, narrow, items, st, error);
 #else
 #define MI_FUSED_CASE(n)                                     \
   case n:                                                    \
     if constexpr (n == MIUPS_ONLY_LOG2K) {                   \
-      return LaunchFused<n>(g, io, f, items, st, error);     \
+      return LaunchFused<n>(g, io, f, narrow, items, st, error); \
     }                                                        \
     break;
 #endif
@@ -338,6 +353,9 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
   f->config_ = config;
   f->taps_ = std::move(taps);
   f->flags_ = flags & kLoadRefCompatSpectrum;  // the only load flag of the public boundary
+  if (std::getenv("MIUPS_EXP_NARROW")) {  // experiment switch (profiles/): one butterfly per thread, 4 waves per SIMD
+    f->flags_ |= kLoadInternalNarrow;
+  }
   f->pool_ = std::make_shared<TablePool>();
   if (!f->SetEq(apoText, fsOut, error)) {  // empty text: the plain filter
     return nullptr;
@@ -420,6 +438,7 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
     geo_ = t.geo;
     hasFused_ = t.hasFused;
     fusedSplit_ = t.fusedSplit;
+    fusedNarrow_ = t.fusedNarrow;
   }
   set->generation = ++generation_;
   cur_ = std::shared_ptr<const TableSet>(set.release(), PoolReturn{pool_});
@@ -768,9 +787,10 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
 void Engine::PickChannelGroup(std::size_t blocks) {
   const Geometry &g = filter_->geometry();
   const int ldsK = filter_->fusedSplit() ? g.K / 2 : g.K;  // transform length held in LDS
-  const int threads = std::max(ldsK / 32, 1);
+  const bool narrow = filter_->fusedNarrow();               // one butterfly per thread, 128 registers: 16 waves per CU
+  const int threads = std::max(ldsK / (narrow ? 16 : 32), 1);
   const int byLds = std::max(1, (160 * 1024) / std::max(ldsK * 8, 1));
-  const int byWaves = std::max(1, 8 / std::max(threads / 64, 1));
+  const int byWaves = std::max(1, (narrow ? 16 : 8) / std::max(threads / 64, 1));
   const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
   wgCapacity_ = std::max<std::size_t>(capacity, 1);
   bool whole = channels_ == 1 || (channels_ == 2 && blocks * streams_ >= capacity);
@@ -942,7 +962,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       ioF.item0 = static_cast<int>(p0 * groups_);
       ioF.scratch = planes;
-      if (!DispatchFused(g, ioF, tabs->fused(), split, static_cast<unsigned>(np * groups_), st, error)) {
+      if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), static_cast<unsigned>(np * groups_), st,
+                         error)) {
         return false;
       }
       if (!ext) {

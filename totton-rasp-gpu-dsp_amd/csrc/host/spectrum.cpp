@@ -81,6 +81,46 @@ void BuildFusedLayout(FilterTables *t) {
   t->hasFused = true;
 }
 
+// Narrow layout (fused_kernel<log2k, EXT, 1>, kernel_fused.h "narrow form"): T = K/16 lanes, lane tid of wave w holds
+// set S_a (lanes 0..31: tau = 32 w + lane) or its mirror S_(J-a) (lanes 32..63, same tau); tau = 0 holds the two
+// self-mirrored sets S_0 and S_(J/2). Per lane: its LDS block in the stride-1 passes (blockB), W_M^k0 (WmT), and for
+// its eight pairs j the spectra of bin k0 + j*J (GT [P][8][T]); G0 [P] = lane 0's ninth pair (bin 8 J = K/2).
+void BuildFusedNarrowLayout(FilterTables *t) {
+  const Geometry &g = t->geo;
+  const int K = g.K, P = g.P, J = K / 16, T = K / 16;
+  std::vector<int> blockOfSet(J);
+  for (int b = 0; b < J; ++b) {
+    blockOfSet[FusedSetOfBlock(b, g.log2k)] = b;
+  }
+  t->WmT.assign(T, cf{1.0f, 0.0f});
+  t->blockB.assign(T, 0);
+  t->GT.assign(static_cast<std::size_t>(P) * 8 * T, f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->G0.assign(static_cast<std::size_t>(P), f4{0.0f, 0.0f, 0.0f, 0.0f});
+  t->Wb = t->Wm[J / 2];
+  auto pair = [&](int p, int k) {
+    const cf gs = t->Gs[static_cast<std::size_t>(p) * K + k];
+    const cf gc = t->Gc[static_cast<std::size_t>(p) * K + k];
+    return f4{gs.x, gs.y, gc.x, gc.y};
+  };
+  for (int tid = 0; tid < T; ++tid) {
+    const int tau = 32 * (tid >> 6) + (tid & 31), mirror = (tid >> 5) & 1;
+    const int a = tau == 0 ? 0 : FusedSetOfBlock(FusedBlockA(tau, g.log2k), g.log2k);  // 0 <= a < J/2
+    const int k0 = mirror ? (tau == 0 ? J / 2 : J - a) : a;
+    t->blockB[tid] = blockOfSet[k0];
+    t->WmT[tid] = t->Wm[k0];
+    for (int p = 0; p < P; ++p) {
+      for (int j = 0; j < 8; ++j) {
+        t->GT[(static_cast<std::size_t>(p) * 8 + j) * T + tid] = pair(p, k0 + j * J);
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p) {
+    t->G0[p] = pair(p, 8 * J);
+  }
+  t->hasFused = true;
+  t->fusedNarrow = true;
+}
+
 // Split layout (fused_split_kernel<log2k - 1>, kernel_fused.h "split form"): thread sets of
 // the half-length transform (Kh = K/2, Jh = Kh/16, T = Kh/32); every half-length mirror
 // pair (k, Kh-k) carries the two full-length pairs (k, K-k) and (Kh-k, Kh+k).
@@ -295,7 +335,12 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
     }
   }
   out->fusedSplit = false;
+  out->fusedNarrow = false;
   if (((flags & kLoadInternalForceSplit) || out->geo.log2k == 15) && BuildFusedSplitLayout(out)) {
+    return true;
+  }
+  if (out->geo.S == 1 && out->geo.log2k >= 10 && out->geo.log2k <= 14 && (flags & kLoadInternalNarrow)) {
+    BuildFusedNarrowLayout(out);  // one butterfly per thread, four waves per SIMD (experiment, see kernel_fused.h)
     return true;
   }
   BuildFusedLayout(out);

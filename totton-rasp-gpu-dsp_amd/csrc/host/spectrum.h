@@ -33,6 +33,9 @@ struct FilterTables {
   // per block transform): T = K/64 threads, GT [P][2][16][T], G0 [P][2][17], selfW [17]. Chosen when
   // K = 32768 (one size past the LDS) and the history length is a multiple of 4.
   bool fusedSplit = false;
+  // fusedNarrow: the layout is for fused_kernel<log2k, EXT, 1> (one butterfly per thread, T = K/16 lanes): WmT [T],
+  // blockB [T] (each lane's own block), GT [P][8][T], G0 [P]. Experiment (kLoadInternalNarrow), 1024 <= K <= 16384.
+  bool fusedNarrow = false;
   std::vector<cf> WmT;      // [T]
   std::vector<int> blockB;  // [T]
   std::vector<f4> GT;       // [P][16][T]
@@ -45,6 +48,9 @@ struct FilterTables {
 // BuildTables flag for the emulation driver only (tests/emu): build the split layout for
 // any K the split kernel covers, so that it can be checked at small sizes.
 constexpr int kLoadInternalForceSplit = 0x100;
+// ... and: the narrow (one butterfly per thread) layout for 1024 <= K <= 16384 (emulation tests and the
+// MIUPS_EXP_NARROW experiment switch; the product uses the wide form, which measured faster: profiles/r02_d_*)
+constexpr int kLoadInternalNarrow = 0x200;
 
 // Frequency layout of the fused kernel's in-place FFT (radices R0,16,..,16,
 // decimation in frequency): after the forward transform LDS block b holds the
