@@ -288,17 +288,27 @@ int main(int argc, char **argv) {
                           : 0;
       IoDesc ioF = io;
       std::vector<float> planar;
-      if (channels > 2) {  // same rule as Engine::ProcessDevice: de-interleave wide frames first
+      // same rules as Engine::ProcessDevice: de-interleave wide frames first; the split form from a split-planar timeline
+      const bool splitPlanar = t.fusedSplit && g.Bc % 4 == 0 && g.hist_frames == g.Oc && g.Oc % 4 == 0 &&
+                               std::getenv("EMU_NO_SPLIT_PLANAR") == nullptr;
+      if (channels > 2 || splitPlanar) {
         const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
         const long long planeFloats = (total + 3) / 4 * 4;
         planar.assign(static_cast<size_t>(planeFloats) * channels * streams, 0.0f);
         const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
-        miups_emu::launch(static_cast<unsigned>(tiles) * streams, 32,
-                          static_cast<size_t>(channels) * (kPlanarTile + 1) * sizeof(float), true,
-                          [&]() { planarize_kernel(g, io, planar.data(), planeFloats, total, tiles); });
+        IoDesc ioP = io;
+        ioP.split_planes = splitPlanar ? 1 : 0;
+        if (splitPlanar && channels <= 2) {
+          miups_emu::launch(Blocks((total + 3) / 4 * streams, 64), 64, 0, false,
+                            [&]() { planarize_quads_kernel(g, ioP, planar.data(), planeFloats, total); });
+        } else {
+          miups_emu::launch(static_cast<unsigned>(tiles) * streams, 32,
+                            static_cast<size_t>(channels) * (kPlanarTile + 1) * sizeof(float), true,
+                            [&]() { planarize_kernel(g, ioP, planar.data(), planeFloats, total, tiles); });
+        }
         ioF.in = planar.data();
         ioF.in_fmt = kF32;
-        ioF.in_planar = 1;
+        ioF.in_planar = splitPlanar ? 2 : 1;
         ioF.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
         ioF.in_stream_stride = ioF.in_plane_stride * channels;
       }

@@ -272,6 +272,28 @@ def test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, fft, ta
             assert np.abs(y[:, s, :, c].reshape(-1) - truth).max() <= 1e-5 * np.abs(truth).max() + lsb
 
 
+@pytest.mark.parametrize("fft,taps,L,channels,in_fmt", [(8192, 2049, 2, 2, "s32"), (16384, 4097, 2, 3, "s16")])
+def test_emulated_split_form_from_interleaved_input(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, channels, in_fmt):
+    """The split form's other input path (EMU_NO_SPLIT_PLANAR = the engine's MIUPS_EXP_NO_SPLIT_PLANAR, and what the
+    engine falls back to when block windows do not start at multiples of four samples): stereo vector loads straight
+    from the caller's PCM / the plain planar timeline, every second complex word per transform half."""
+    monkeypatch.setenv("EMU_SPLIT", "1")
+    monkeypatch.setenv("EMU_NO_SPLIT_PLANAR", "1")
+    rng = np.random.default_rng(fft + L + 1)
+    h = (rng.standard_normal(taps) * 0.01).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks, calls = block // L, 2, 2
+    xf = np.clip(rng.standard_normal((calls, 1, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    raw = O.float_to_pcm(xf.reshape(-1), in_fmt).tobytes()
+    xin = O.pcm_to_float(np.frombuffer(raw, np.uint8), in_fmt).reshape(xf.shape)
+    out = run_emu(emu, tmp_path, p, raw, 1, channels, blocks, calls, "fused", in_fmt, "f32")
+    y = np.frombuffer(out, np.float32).reshape(calls, 1, blocks * block, channels)
+    for c in range(channels):
+        truth = O.truth_stream(xin[:, 0, :, c].reshape(-1), h, L, calls * blocks, block).reshape(-1)
+        assert np.abs(y[:, 0, :, c].reshape(-1) - truth).max() <= 1e-5 * np.abs(truth).max()
+
+
 def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
     """44k 4x shipped filter, one stereo block through both kernel families."""
     path = ROOT / "tests" / "golden" / "filters" / "filter_44k_4x_80000_min_phase.json"

@@ -246,7 +246,7 @@ struct IoDesc {
   // fused path, more than two channels: `in` is not the caller's interleaved PCM
   // but the engine's planar copy made by planarize_kernel -- one fp32 timeline
   // (history ++ new frames) per channel, in_plane_stride bytes apart, in_fmt = f32.
-  int in_planar;
+  int in_planar;         // 1: plain timeline; 2: split-planar (split form, block windows start at multiples of 4)
   long long in_plane_stride;
   // fused path with groups narrower than a frame (cg < channels): the kernel stops after
   // the staging planes (ext_epilogue = 1) and interleave_*_kernel turns each chunk of

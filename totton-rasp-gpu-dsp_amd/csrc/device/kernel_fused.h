@@ -75,6 +75,11 @@ __device__ unsigned long long mi_stamps[32][8][192];
 #define MI_STAMP(id)
 #endif
 
+#if defined(MIUPS_EXP_SKIP_PAIR_SYNC)  // timing experiment (profiles/r02_d_*): no barrier inside a pair of passes (WRONG results)
+#define MI_SYNC_PAIR() do {} while (0)
+#else
+#define MI_SYNC_PAIR() MI_SYNC()
+#endif
 namespace miups {
 
 // exp(-2*pi*i*t/32), t = 0..16
@@ -206,7 +211,10 @@ struct BlockIo {
   // samples of a complex input word are one 8-byte load. 2: stereo, 4-byte
   // samples, 16-byte aligned -> two whole frames are one 16-byte load (lanes read
   // consecutive 16-byte words: full cache lines) and the channel is picked from it.
+  // 3: split-planar fp32 timeline (IoDesc::in_planar == 2): the complex words of transform half h are contiguous,
+  // word q at pin + h * half_stride + 8 q -- lanes read consecutive 8-byte words.
   int vec_mode;
+  long long half_stride;
   int chan;
   // split form (K = 2 * the LDS transform length): the transform in flight takes the complex
   // words 2n + half, i.e. compact samples 4n + noff, 4n + noff + 1 (noff = 0 or 2)
@@ -217,6 +225,23 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
   BlockIo b;
   const long long ib = pcm_bytes(io.in_fmt);
   const long long f0 = static_cast<long long>(blk) * g.Bc - g.Oc;
+  b.half_stride = 0;
+  if (io.in_planar == 2) {
+    // split-planar fp32 timeline (planarize_kernel with io.split_planes): sample i of the timeline sits at float
+    // (i & 2 ? H : 0) + 2 (i >> 2) + (i & 1), H = half a plane. The host takes this layout only when every block's
+    // window starts at a multiple of four samples.
+    const long long i0 = g.hist_frames + f0;
+    b.in_step = 4;
+    b.pin = static_cast<const char *>(io.in) + s * io.in_stream_stride + c * io.in_plane_stride + (i0 >> 1) * 4;
+    b.phist = b.pin;
+    b.half_stride = io.in_plane_stride >> 1;
+    b.n_hist = 0;
+    b.Oc = g.Oc;
+    b.chan = 0;
+    b.noff = 0;
+    b.vec_mode = 3;
+    return b;
+  }
   if (io.in_planar) {
     // planar fp32 timeline: index hist_frames + f holds frame f of this call
     b.in_step = 4;
@@ -282,10 +307,15 @@ struct FusedCfg {
 // stride S (sub-transform length L = S*R): base = (q / S) * L + q % S.
 // The four strides that occur (K/R0 = 16^N16, 256, 16, 1) each get the cheapest
 // closed form of lds_swz(base + t*S).
+// byte(t) = 8 * at(t) in the form that costs the fewest address instructions (the passes are VALU-issue bound and the
+// generic form spent ~2 instructions per LDS access, a fifth of a pass): strides 1 and 16: one XOR with a constant
+// per access; stride 256: the swizzle term takes four values, so four bases per butterfly and every
+// access is base + immediate offset; stride >= 1024: one base + immediate offsets.
 template <int R, int S>
 struct Bfly {
   int p;  // precomputed per butterfly
   int w;  // S == 16 only
+  int b4[S == 256 ? 4 : 1];  // S == 256: byte address of (p ^ swizzle term k)
   MI_DEVICE explicit Bfly(int q) {
     if constexpr (S == 1) {
       p = lds_swz(16 * q);
@@ -303,6 +333,14 @@ struct Bfly {
       p = lds_swz(base);
       w = 0;
     }
+    if constexpr (S == 256) {
+      MI_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        b4[k] = (p ^ (((k & 1) << 3) | ((k >> 1) << 4))) * 8;
+      }
+    } else {
+      b4[0] = 0;
+    }
   }
   MI_DEVICE int at(int t) const {
     if constexpr (S == 1) {
@@ -317,6 +355,17 @@ struct Bfly {
       return p + t * S;
     }
   }
+  MI_DEVICE int byte(int t) const {
+    if constexpr (S == 1) {
+      return (p * 8) ^ (t * 8);
+    } else if constexpr (S == 16) {
+      return ((p + w) * 8) ^ (136 * t);  // p holds bits >= 8 only and (17 t) ^ w < 256: the sum is an XOR
+    } else if constexpr (S == 256) {
+      return b4[(t & 1) | (((t ^ (t >> 1)) & 1) << 1)] + t * (S * 8);
+    } else {
+      return p * 8 + t * (S * 8);
+    }
+  }
 };
 
 template <int LOG2K, int W = 2>
@@ -326,11 +375,15 @@ struct FusedKernel {
   static constexpr int LOG2R0 = Cfg::LOG2R0;
   static constexpr int S0 = K / R0;  // stride of the radix-R0 pass (= 16^N16)
 
+  static MI_DEVICE const cf &lds_ref(const cf *lds, int byte) {
+    return *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(lds) + byte);
+  }
+  static MI_DEVICE cf &lds_ref(cf *lds, int byte) { return *reinterpret_cast<cf *>(reinterpret_cast<char *>(lds) + byte); }
   template <int R, int S>
   static MI_DEVICE void lds_get(const cf *lds, const Bfly<R, S> &b, cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
-      v[t] = lds[b.at(t)];
+      v[t] = lds_ref(lds, b.byte(t));
     }
   }
   // natural order in v
@@ -338,7 +391,7 @@ struct FusedKernel {
   static MI_DEVICE void lds_put(cf *lds, const Bfly<R, S> &b, const cf *v) {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
-      lds[b.at(t)] = v[t];
+      lds_ref(lds, b.byte(t)) = v[t];
     }
   }
   // v holds dftR output (element u at v[out_pos<R>(u)])
@@ -346,7 +399,7 @@ struct FusedKernel {
   static MI_DEVICE void lds_put_dft(cf *lds, const Bfly<R, S> &b, const cf *v) {
     MI_UNROLL
     for (int u = 0; u < R; ++u) {
-      lds[b.at(u)] = v[out_pos<R>(u)];
+      lds_ref(lds, b.byte(u)) = v[out_pos<R>(u)];
     }
   }
 
@@ -365,7 +418,13 @@ struct FusedKernel {
     MI_UNROLL
     for (int t = 0; t < R; ++t) {
       const int n = SP ? 4 * (q + t * (K / R)) + b.noff : 2 * (q + t * (K / R));
-      if constexpr (MODE == 1) {
+      if constexpr (MODE == 3) {
+        static_assert(MODE != 3 || (SP == 1 && FMT == kF32), "split-planar input is fp32 and belongs to the split form");
+        const cf w = *reinterpret_cast<const cf *>(b.pin + (b.noff >> 1) * b.half_stride +
+                                                   static_cast<unsigned>(q + t * (K / R)) * 8u);
+        v[t] = w;
+        continue;
+      } else if constexpr (MODE == 1) {
         struct alignas(8) W2 {
           int32_t a, b;
         };
@@ -397,6 +456,40 @@ struct FusedKernel {
         v[t] = mk(sample_load<FMT>(p0), sample_load<FMT>(p1));
       } else {
         v[t] = mk(sample_load<FMT>(b.pin + o0), sample_load<FMT>(b.pin + o1));
+      }
+    }
+  }
+  // The vector modes in two steps, so that a first pass can request ALL of a thread's input words before it converts
+  // the first one (fwd_first): Raw = the loaded bytes (MODE 2: two whole stereo frames, else one complex word).
+  template <int MODE>
+  struct alignas(MODE == 2 ? 16 : 8) Raw {
+    int32_t w[MODE == 2 ? 4 : 2];
+  };
+  template <int R, int MODE, int SP>
+  static MI_DEVICE void global_fetch(const BlockIo &b, int q, Raw<MODE> *r) {
+    MI_UNROLL
+    for (int t = 0; t < R; ++t) {
+      const unsigned word = static_cast<unsigned>(q + t * (K / R));  // complex word of this transform
+      const unsigned n = SP ? 4u * word + static_cast<unsigned>(b.noff) : 2u * word;
+      if constexpr (MODE == 3) {
+        r[t] = *reinterpret_cast<const Raw<MODE> *>(b.pin + (b.noff >> 1) * b.half_stride + word * 8u);
+      } else if constexpr (MODE == 1) {
+        r[t] = *reinterpret_cast<const Raw<MODE> *>(b.pin + n * 4u);
+      } else {
+        r[t] = *reinterpret_cast<const Raw<MODE> *>(b.pin - 4 * b.chan + n * 8u);
+      }
+    }
+  }
+  template <int FMT, int R, int MODE>
+  static MI_DEVICE void global_unpack(const BlockIo &b, const Raw<MODE> *r, cf *v) {
+    MI_UNROLL
+    for (int t = 0; t < R; ++t) {
+      const int32_t lo = MODE == 2 ? (b.chan ? r[t].w[1] : r[t].w[0]) : r[t].w[0];
+      const int32_t hi = MODE == 2 ? (b.chan ? r[t].w[3] : r[t].w[2]) : r[t].w[1];
+      if constexpr (FMT == kF32) {
+        v[t] = mk(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+      } else {
+        v[t] = mk(static_cast<float>(lo) * (1.0f / 2147483648.0f), static_cast<float>(hi) * (1.0f / 2147483648.0f));
       }
     }
   }
@@ -481,7 +574,27 @@ struct FusedKernel {
   static MI_DEVICE void fwd_first(const BlockIo &b, cf *lds, const cf *tw, int tid) {
     // W_K^(tid + i*T) = W_K^tid * W_(16W)^i : one table load for all butterflies
     const cf w0 = load_tw<LOG2K>(tw, tid);
-    if constexpr (R0 > 1) {
+    if constexpr (R0 > 1 && MODE != 0) {
+      // every input word of the thread (16 W of them) is requested before the first one is converted -- the fence pins
+      // that order; the scheduler otherwise interleaves loads and conversions as register pressure suggests to it and
+      // the round trips queue up (same source, other builds: 12.3k .. 16.3k cycles, profiles/r02_d_*)
+      constexpr int NB = 16 * W / R0;
+      Raw<MODE> in[NB][R0];
+      MI_UNROLL
+      for (int i = 0; i < NB; ++i) {
+        global_fetch<R0, MODE, SP>(b, tid + i * T, in[i]);
+      }
+      MI_SCHED_FENCE();
+      MI_UNROLL
+      for (int i = 0; i < NB; ++i) {
+        const int q = tid + i * T;
+        cf v[R0];
+        global_unpack<FMT, R0, MODE>(b, in[i], v);
+        dftR<-1, R0>(v);
+        apply_twiddles_out<-1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
+        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), v);
+      }
+    } else if constexpr (R0 > 1) {
       // every input load of the thread is issued before the first butterfly, so the
       // HBM round trip is paid once, not once per butterfly
       constexpr int NB = 16 * W / R0;
@@ -497,6 +610,21 @@ struct FusedKernel {
         apply_twiddles_out<-1, R0>(raw[i], i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
         lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), raw[i]);
       }
+    } else if constexpr (W == 2 && MODE != 0) {
+      Raw<MODE> ia[16], ib[16];
+      global_fetch<16, MODE, SP>(b, tid, ia);
+      global_fetch<16, MODE, SP>(b, tid + T, ib);
+      MI_SCHED_FENCE();
+      cf A[16], B[16];
+      global_unpack<FMT, 16, MODE>(b, ia, A);
+      dft16<-1>(A);
+      apply_twiddles_out<-1, 16>(A, w0);
+      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      MI_SCHED_FENCE();
+      global_unpack<FMT, 16, MODE>(b, ib, B);
+      dft16<-1>(B);
+      apply_twiddles_out<-1, 16>(B, cmul(w0, w32(1)));
+      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
     } else if constexpr (W == 1) {
       cf A[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
@@ -518,6 +646,12 @@ struct FusedKernel {
   }
   template <int FMT, int SP = 0>
   static MI_DEVICE void fwd_first_fmt(const BlockIo &b, cf *lds, const cf *tw, int tid) {
+    if constexpr (FMT == kF32 && SP == 1) {
+      if (b.vec_mode == 3) {
+        fwd_first<FMT, false, 3, SP>(b, lds, tw, tid);
+        return;
+      }
+    }
     if constexpr (FMT == kS32 || FMT == kF32) {
       if (b.vec_mode == 2) {
         fwd_first<FMT, false, 2, SP>(b, lds, tw, tid);
@@ -688,10 +822,31 @@ struct FusedKernel {
   static MI_DEVICE void phase_inputs(int tid, const cf *Xa, const cf *Xb, cf Wa, cf Wa2, cf Wb, const f4 *MI_RESTRICT gt,
                                      const f4 *MI_RESTRICT g0, cf *A, cf *B) {
     // pair t: k = a + t*J  <->  K-k = (J-a) + (15-t)*J
+    // The sixteen table words in four groups of four, group g+1 requested before group g is used (two groups = 32
+    // registers in flight), each group's loads fenced ahead of the arithmetic: left to itself the scheduler sometimes
+    // issues load, wait, use, load, wait, use -- sixteen exposed L2 round trips, 3.6k -> 6.8k cycles per phase
+    // (profiles/r02_d_phase_loads.txt; which schedule came out depended on unrelated code elsewhere in the kernel).
     const f4 *pg = gt + tid;
+    f4 gv[2][4];
     MI_UNROLL
-    for (int t = 0; t < 16; ++t) {
-      pair_phase(Xa[t], Xb[t], slot_twiddle(t, Wa, Wa2), pg[t * T], A[t], B[15 - t]);
+    for (int j = 0; j < 4; ++j) {
+      gv[0][j] = pg[j * T];
+    }
+    MI_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      if (q < 3) {
+        MI_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          gv[(q + 1) & 1][j] = pg[(4 * (q + 1) + j) * T];
+        }
+      }
+      MI_SCHED_FENCE();
+      MI_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * q + j;
+        pair_phase(Xa[t], Xb[t], slot_twiddle(t, Wa, Wa2), gv[q & 1][j], A[t], B[15 - t]);
+      }
+      MI_SCHED_FENCE();
     }
     if (tid == 0) {
       // slot s <= 8: zk is A[s] already, zkm belongs at A[16-s] (s = 1..7; DC and the self-mirrored bin have none);
@@ -900,24 +1055,41 @@ struct FusedKernel {
   static MI_DEVICE void phase_inputs2(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, const cf *Xs,
                                       cf Wa, cf Ws, const SelfLane &sl, const f4 *MI_RESTRICT gt,
                                       const f4 *MI_RESTRICT g0, cf *lds, const Bfly<16, 1> &bA, const Bfly<16, 1> &bB) {
+    // Table words in eight groups of two slots (4 words), group g+1 requested before group g is used and each group's
+    // loads fenced ahead of its arithmetic (8 words = 32 registers in flight beside the 128 of the spectrum): see
+    // phase_inputs -- left alone the scheduler serialises load, wait, use (19.9k cycles per call instead of ~8k).
     const f4 *pg = gt + tid;
+    f4 gv[2][4];
+    auto request = [&](int q) {
+      MI_UNROLL
+      for (int j = 0; j < 2; ++j) {
+        gv[q & 1][2 * j] = pg[(2 * q + j) * T];
+        gv[q & 1][2 * j + 1] = pg[(16 + 2 * q + j) * T];
+      }
+    };
+    request(0);
     MI_UNROLL
-    for (int t = 0; t < 16; ++t) {
-      cf ok, om;
-#if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table loads (wrong results)
-      quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
-                    f4{0.5f, 0.0f, 0.5f, 0.0f}, ok, om);
-      (void)pg;
+    for (int q = 0; q < 8; ++q) {
+      if (q < 7) {
+        request(q + 1);
+      }
+      MI_SCHED_FENCE();
+      MI_UNROLL
+      for (int j = 0; j < 2; ++j) {
+        const int t = 2 * q + j;
+        cf ok, om;
+#if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table words (wrong results)
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
+                      f4{0.5f, 0.0f, 0.5f, 0.0f}, ok, om);
 #else
-      quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), pg[t * T], pg[(16 + t) * T], ok, om);
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), gv[q & 1][2 * j], gv[q & 1][2 * j + 1], ok, om);
 #endif
-      if (tid != 0) {
-        lds[bA.at(t)] = ok;
-        lds[bB.at(15 - t)] = om;
+        if (tid != 0) {
+          lds[bA.at(t)] = ok;
+          lds[bB.at(15 - t)] = om;
+        }
       }
-      if ((t & 3) == 3) {
-        MI_SCHED_FENCE();  // at most 8 table words in flight: the spectrum already holds 128 registers
-      }
+      MI_SCHED_FENCE();
     }
     if (tid < kSelfLanes) {
       cf ok, om;
@@ -1280,7 +1452,7 @@ struct FusedKernel {
       default: fwd_first_fmt<kS24_3LE>(b, lds, ft.tw, tid); break;
     }
     MI_STAMP(sb + 1);
-    MI_SYNC();
+    MI_SYNC_PAIR();
     MI_STAMP(sb + 2);
     // radix-16 passes with strides 256 and 16 exist when K/R0 >= 4096 resp. >= 256
     // (when R0 == 1 the first pass already was the stride-K/16 radix-16 pass)
@@ -1294,7 +1466,7 @@ struct FusedKernel {
     if constexpr (kFirstMidStride >= 16) {
       fwd_mid<16>(lds, ft.tw, tid);
       MI_STAMP(sb + 5);
-      MI_SYNC();
+      MI_SYNC_PAIR();
       MI_STAMP(sb + 6);
     }
     const bool evenOc = (b.Oc & 1) == 0;
@@ -1329,7 +1501,7 @@ struct FusedKernel {
         dft16<+1>(V);
         lds_put_dft<16, 1>(lds, Bfly<16, 1>(bk), V);
         MI_STAMP(sp + 1);
-        MI_SYNC();
+        MI_SYNC_PAIR();
         MI_STAMP(sp + 2);
         if constexpr (kFirstMidStride >= 16) {
           MI_OPAQUE_VGPR(tl);
@@ -1342,7 +1514,7 @@ struct FusedKernel {
           MI_OPAQUE_VGPR(tl);
           inv_mid<256>(lds, ft.tw, tl);
           MI_STAMP(sp + 5);
-          MI_SYNC();
+          MI_SYNC_PAIR();
           MI_STAMP(sp + 6);
         }
         MI_OPAQUE_VGPR(tl);
@@ -1398,7 +1570,7 @@ struct FusedKernel {
       MI_OPAQUE_VGPR(bb);
       inv_first(lds, ba, bb, A, B);
       MI_STAMP(sp + 1);
-      MI_SYNC();
+      MI_SYNC_PAIR();
       MI_STAMP(sp + 2);
       if constexpr (kFirstMidStride >= 16) {
         MI_OPAQUE_VGPR(tl);
@@ -1411,7 +1583,7 @@ struct FusedKernel {
         MI_OPAQUE_VGPR(tl);
         inv_mid<256>(lds, ft.tw, tl);
         MI_STAMP(sp + 5);
-        MI_SYNC();
+        MI_SYNC_PAIR();
         MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
@@ -1621,7 +1793,8 @@ struct FusedKernel {
     MI_STAMP(128);
     // every plane store of this workgroup is complete and visible to it
     // (the loop ends in a workgroup barrier, which carries the release/acquire)
-    if constexpr (!SPLIT && !EXT) {  // the split form always leaves the frames to interleave_*_kernel
+    if constexpr (!SPLIT && !EXT) {  // the split form always leaves the frames to interleave_*_kernel (its own epilogue
+                                     // measured no faster than the separate pass: profiles/r02_d_*)
       epilogue(g, io, s, c0, blk, scr, lds, tid);
     }
     MI_STAMP(129);

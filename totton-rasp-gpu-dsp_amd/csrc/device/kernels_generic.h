@@ -189,8 +189,69 @@ MI_GLOBAL void planarize_kernel(Geometry g, IoDesc io, float *MI_RESTRICT planar
     const int c = e / kPlanarTile, f = e - c * kPlanarTile;
     const long long t = t0 + f;
     if (t < total_frames) {
-      planar[(static_cast<long long>(s) * C + c) * plane_floats + t] = tile[c * (kPlanarTile + 1) + f];
+      // io.split_planes: split-planar order (see make_block_io) -- even complex words in the first half of the plane,
+      // odd ones in the second
+      const long long at = io.split_planes ? ((t & 2) ? (plane_floats >> 1) : 0) + ((t >> 2) << 1) + (t & 1) : t;
+      planar[(static_cast<long long>(s) * C + c) * plane_floats + at] = tile[c * (kPlanarTile + 1) + f];
     }
+  }
+}
+
+// Mono / stereo frames -> split-planar timeline (make_block_io, in_planar == 2), one quad of frames per thread:
+// timeline samples 4m..4m+3 of every channel in (one 32-byte read per lane for 4-byte stereo), the even complex word
+// (samples 4m, 4m+1) to float 2m of the plane's first half and the odd one (4m+2, 4m+3) to float 2m of its second half
+// out -- consecutive lanes read and write consecutive memory. The host guarantees hist_frames % 4 == 0, so a quad
+// never straddles the history / new-input boundary. (planarize_kernel's LDS tiles are [channels][64] floats: for two
+// channels that is a 512-byte workgroup, hundreds of thousands of them per call.)
+MI_GLOBAL void planarize_quads_kernel(Geometry g, IoDesc io, float *MI_RESTRICT planar, long long plane_floats,
+                                      long long total_frames) {
+  const long long quads = (total_frames + 3) >> 2;
+  const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
+  if (gid >= quads * io.streams) {
+    return;
+  }
+  const int s = static_cast<int>(gid / quads);
+  const long long m = gid - s * quads, t0 = 4 * m;
+  const int C = io.channels;
+  const bool from_hist = t0 < g.hist_frames;
+  const char *src = from_hist ? static_cast<const char *>(io.hist) + s * io.hist_stream_stride
+                              : static_cast<const char *>(io.in) + s * io.in_stream_stride;
+  const long long f0 = from_hist ? t0 : t0 - g.hist_frames;  // first frame of the quad in that buffer
+  const long long limit = from_hist ? g.hist_frames : total_frames - g.hist_frames;
+  float v[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+  const char *q = src + f0 * C * pcm_bytes(io.in_fmt);
+  if ((io.in_fmt == kS32 || io.in_fmt == kF32) && f0 + 4 <= limit && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+    struct alignas(16) W4 {
+      int32_t w[4];
+    };
+    MI_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      if (k < C) {  // C * 16 bytes = the quad
+        const W4 w = *reinterpret_cast<const W4 *>(q + 16 * k);
+        MI_UNROLL
+        for (int e = 0; e < 4; ++e) {
+          const int idx = 4 * k + e, f = C == 2 ? idx >> 1 : idx, c = C == 2 ? idx & 1 : 0;
+          v[f][c] = io.in_fmt == kF32 ? __builtin_bit_cast(float, w.w[e])
+                                      : static_cast<float>(w.w[e]) * (1.0f / 2147483648.0f);
+        }
+      }
+    }
+  } else {
+    MI_UNROLL
+    for (int f = 0; f < 4; ++f) {
+      if (f0 + f < limit) {
+        v[f][0] = pcm_load(src, io.in_fmt, (f0 + f) * C);
+        if (C == 2) {
+          v[f][1] = pcm_load(src, io.in_fmt, (f0 + f) * C + 1);
+        }
+      }
+    }
+  }
+  const long long half = plane_floats >> 1;
+  for (int c = 0; c < C; ++c) {
+    float *plane = planar + (static_cast<long long>(s) * C + c) * plane_floats;
+    *reinterpret_cast<cf *>(plane + 2 * m) = mk(v[0][c], v[1][c]);
+    *reinterpret_cast<cf *>(plane + half + 2 * m) = mk(v[2][c], v[3][c]);
   }
 }
 

@@ -918,7 +918,12 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
                         ? 1
                         : 0;
     IoDesc ioF = io;  // what the fused kernel reads (io keeps the caller's buffers for the history carry)
-    if (channels_ > 2 && channels_ <= kMaxPlanarChannels) {
+    // The split form reads every second complex word per transform half: from interleaved stereo PCM that is 8 useful
+    // bytes per 32 (measured: its two first passes were 36 % of the kernel, profiles/r02_d_*); from a split-planar
+    // timeline the lanes read consecutive 8-byte words.
+    const bool splitPlanar = split && g.Bc % 4 == 0 && g.hist_frames == g.Oc && g.Oc % 4 == 0 &&
+                             std::getenv("MIUPS_EXP_NO_SPLIT_PLANAR") == nullptr;  // experiment switch (profiles/)
+    if ((channels_ > 2 || splitPlanar) && channels_ <= kMaxPlanarChannels) {
       // wide frames: de-interleave (history ++ new frames) once, coalesced, instead of
       // gathering one sample per cache line in every channel's first pass
       const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
@@ -934,14 +939,22 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
       const std::size_t lds = static_cast<std::size_t>(channels_) * (kPlanarTile + 1) * sizeof(float);
-      hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, io,
-                         planar_, planeFloats, total, tiles);
+      IoDesc ioP = io;
+      ioP.split_planes = splitPlanar ? 1 : 0;
+      if (splitPlanar && channels_ <= 2) {
+        const long long quads = (total + 3) / 4 * streams_;
+        hipLaunchKernelGGL(planarize_quads_kernel, dim3(Blocks(quads, 256)), dim3(256), 0, st, g, ioP, planar_,
+                           planeFloats, total);
+      } else {
+        hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
+                           planar_, planeFloats, total, tiles);
+      }
       if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
         return false;
       }
       ioF.in = planar_;
       ioF.in_fmt = kF32;
-      ioF.in_planar = 1;
+      ioF.in_planar = splitPlanar ? 2 : 1;
       ioF.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
       ioF.in_stream_stride = ioF.in_plane_stride * channels_;
     }
