@@ -160,6 +160,37 @@ void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, u
   miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
 }
 
+// interleave_tiled_kernel with the engine's 256-thread shape (EPT = rows * TI / 1024)
+template <int FMT, int TI>
+void EmuInterleaveTiledEpt(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ept) {
+  const int rows = g.P * io.channels;
+  const unsigned grid = static_cast<unsigned>(nb) * static_cast<unsigned>(tiles);
+  const size_t lds = static_cast<size_t>(rows) * (TI + 1) * sizeof(float);
+  auto run = [&](auto kernel) { miups_emu::launch(grid, 256, lds, true, [&]() { kernel(g, io, planes, sb0, nb, tiles); }); };
+  switch (ept) {
+    case 1: run(interleave_tiled_kernel<FMT, TI, 1>); break;
+    case 2: run(interleave_tiled_kernel<FMT, TI, 2>); break;
+    case 3: run(interleave_tiled_kernel<FMT, TI, 3>); break;
+    case 4: run(interleave_tiled_kernel<FMT, TI, 4>); break;
+    case 5: run(interleave_tiled_kernel<FMT, TI, 5>); break;
+    case 6: run(interleave_tiled_kernel<FMT, TI, 6>); break;
+    case 7: run(interleave_tiled_kernel<FMT, TI, 7>); break;
+    default: run(interleave_tiled_kernel<FMT, TI, 8>); break;
+  }
+}
+void EmuInterleaveTiled(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ti, int ept,
+                        bool f32) {
+  if (f32) {
+    if (ti == 64) EmuInterleaveTiledEpt<kF32, 64>(g, io, planes, sb0, nb, tiles, ept);
+    else if (ti == 32) EmuInterleaveTiledEpt<kF32, 32>(g, io, planes, sb0, nb, tiles, ept);
+    else EmuInterleaveTiledEpt<kF32, 16>(g, io, planes, sb0, nb, tiles, ept);
+  } else {
+    if (ti == 64) EmuInterleaveTiledEpt<kS32, 64>(g, io, planes, sb0, nb, tiles, ept);
+    else if (ti == 32) EmuInterleaveTiledEpt<kS32, 32>(g, io, planes, sb0, nb, tiles, ept);
+    else EmuInterleaveTiledEpt<kS32, 16>(g, io, planes, sb0, nb, tiles, ept);
+  }
+}
+
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   if (t.fusedSplit) {  // two half-length transforms per block transform
     switch (g.log2k - 1) {
@@ -322,7 +353,20 @@ int main(int argc, char **argv) {
         if (!ext) {
           continue;
         }
-        if (quad) {
+        const int rows = g.P * channels;
+        int tiledTi = 0;  // same rule as the engine (its 256 threads are 32 here: EPT is 8x the engine's)
+        if (quad && !t.fusedSplit && rows >= 16 && !std::getenv("EMU_NO_TILED_INTERLEAVE")) {
+          tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
+          const int per = 1024 / tiledTi;
+          if (rows % per != 0 || rows / per > 8 || rows > 512) {
+            tiledTi = 0;
+          }
+        }
+        if (tiledTi) {
+          const int tiles = (g.Bc + tiledTi - 1) / tiledTi;
+          EmuInterleaveTiled(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np), tiles, tiledTi,
+                             rows * tiledTi / 1024, outFmt == kF32);
+        } else if (quad) {
           const int threads = 32, perWg = threads * 4;
           const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels / 4);
           const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);

@@ -272,6 +272,34 @@ def test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, fft, ta
             assert np.abs(y[:, s, :, c].reshape(-1) - truth).max() <= 1e-5 * np.abs(truth).max() + lsb
 
 
+@pytest.mark.parametrize("fft,taps,L,channels,out_fmt,tiled", [
+    (8192, 2113, 4, 8, "s32", True),     # 32 rows, Bc = 1520: the last 64-wide tile is partial
+    (4096, 1025, 16, 16, "f32", True),   # 256 rows: 32-wide tiles
+    (4096, 1025, 8, 12, "s32", True),    # 96 rows (not a power of two)
+    (4096, 1025, 2, 8, "s32", False),    # the quad form where the tiled one would be chosen
+])
+def test_emulated_interleave_kernels_for_wide_frames(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, channels,
+                                                     out_fmt, tiled):
+    """interleave_tiled_kernel (LDS-tiled staging planes -> frames, the form the engine takes for 16 or more planes per
+    frame group) and, with EMU_NO_TILED_INTERLEAVE (= the engine's MIUPS_EXP_NO_TILED_INTERLEAVE), the quad form on the
+    same shapes: every channel against fp64 truth, which also pins the row order (phase-major, channel-minor)."""
+    if not tiled:
+        monkeypatch.setenv("EMU_NO_TILED_INTERLEAVE", "1")
+    rng = np.random.default_rng(fft + L + channels)
+    h = (rng.standard_normal(taps) * 0.01).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin, blocks = block // L, 2
+    x = np.clip(rng.standard_normal((1, 1, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    out = run_emu(emu, tmp_path, p, x.tobytes(), 1, channels, blocks, 1, "fused", "f32", out_fmt)
+    y = np.frombuffer(out, np.float32) if out_fmt == "f32" else O.pcm_to_float(np.frombuffer(out, np.uint8), out_fmt)
+    y = y.reshape(blocks * block, channels)
+    lsb = 0.0 if out_fmt == "f32" else 2.0**-31
+    for c in range(channels):
+        truth = O.truth_stream(x[0, 0, :, c], h, L, blocks, block).reshape(-1)
+        assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + lsb
+
+
 @pytest.mark.parametrize("fft,taps,L,channels,in_fmt", [(8192, 2049, 2, 2, "s32"), (16384, 4097, 2, 3, "s16")])
 def test_emulated_split_form_from_interleaved_input(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, channels, in_fmt):
     """The split form's other input path (EMU_NO_SPLIT_PLANAR = the engine's MIUPS_EXP_NO_SPLIT_PLANAR, and what the

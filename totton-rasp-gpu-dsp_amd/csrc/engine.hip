@@ -195,6 +195,48 @@ bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const FusedTables &ft
   return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
 }
 
+// interleave_tiled_kernel<FMT, TI, EPT>: TI in {64, 32, 16}, EPT = rows * TI / 1024 in 1..8
+template <int FMT, int TI>
+bool LaunchInterleaveTiledEpt(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ept,
+                              hipStream_t st) {
+  const int rows = g.P * io.channels;
+  const dim3 grid(static_cast<unsigned>(nb) * static_cast<unsigned>(tiles)), block(256);
+  const std::size_t lds = static_cast<std::size_t>(rows) * (TI + 1) * sizeof(float);
+  switch (ept) {
+#define MI_TILED_CASE(n)                                                                                             \
+  case n:                                                                                                            \
+    hipLaunchKernelGGL((interleave_tiled_kernel<FMT, TI, n>), grid, block, lds, st, g, io, planes, sb0, nb, tiles); \
+    return true;
+    MI_TILED_CASE(1)
+    MI_TILED_CASE(2)
+    MI_TILED_CASE(3)
+    MI_TILED_CASE(4)
+    MI_TILED_CASE(5)
+    MI_TILED_CASE(6)
+    MI_TILED_CASE(7)
+    MI_TILED_CASE(8)
+#undef MI_TILED_CASE
+    default: return false;
+  }
+}
+bool LaunchInterleaveTiled(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ti,
+                           int ept, bool f32, hipStream_t st) {
+  if (f32) {
+    switch (ti) {
+      case 64: return LaunchInterleaveTiledEpt<kF32, 64>(g, io, planes, sb0, nb, tiles, ept, st);
+      case 32: return LaunchInterleaveTiledEpt<kF32, 32>(g, io, planes, sb0, nb, tiles, ept, st);
+      case 16: return LaunchInterleaveTiledEpt<kF32, 16>(g, io, planes, sb0, nb, tiles, ept, st);
+      default: return false;
+    }
+  }
+  switch (ti) {
+    case 64: return LaunchInterleaveTiledEpt<kS32, 64>(g, io, planes, sb0, nb, tiles, ept, st);
+    case 32: return LaunchInterleaveTiledEpt<kS32, 32>(g, io, planes, sb0, nb, tiles, ept, st);
+    case 16: return LaunchInterleaveTiledEpt<kS32, 16>(g, io, planes, sb0, nb, tiles, ept, st);
+    default: return false;
+  }
+}
+
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, bool narrow, unsigned items,
                    hipStream_t st, std::string *error) {
   if (split) {
@@ -989,7 +1031,28 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         ist = aux;
       }
       // staging planes of this chunk -> interleaved PCM frames
-      if (quad) {
+      const int rows = g.P * channels_;
+      int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
+      if (quad && !split && rows >= 16 && std::getenv("MIUPS_EXP_NO_TILED_INTERLEAVE") == nullptr) {  // experiment switch
+        tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
+        if (const char *ti = std::getenv("MIUPS_EXP_TILE_TI")) {  // experiment switch (profiles/): tile width 16 / 32 / 64
+          tiledTi = std::atoi(ti);
+        }
+        const int per = 1024 / tiledTi;  // rows per 16-byte word of a 256-thread pass over the tile
+        if (rows % per != 0 || rows / per > 8 || rows > 512) {
+          tiledTi = 0;
+        }
+      }
+      if (tiledTi) {
+        const int tiles = (g.Bc + tiledTi - 1) / tiledTi;
+        if (!LaunchInterleaveTiled(g, ioF, planes, static_cast<int>(p0), static_cast<int>(np), tiles, tiledTi,
+                                   rows * tiledTi / 1024, outFmt_ == kF32, ist)) {
+          if (error) {
+            *error = "interleave_tiled_kernel: no instantiation for this frame shape";
+          }
+          return false;
+        }
+      } else if (quad) {
         const int threads = 256, perWg = threads * 4;  // interleave_quad_kernel: kUnits = 4
         const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels_ / 4);
         const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
