@@ -11,6 +11,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 SRC = ROOT / "gpurun_out" / "r02"
+PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02_e"  # profiles/<PREFIX>_pmc_<tag>.txt
 TAGS = {"c2_256": ("2", 1, 2, 256), "c2_2048": ("2_2048blocks", 1, 2, 2048), "c3": ("3", 1, 8, 256), "c4": ("4", 32, 2, 32),
         "c5": ("5", 1, 32, 64)}
 
@@ -44,8 +45,8 @@ def main():
                              "bytes_per_step": int(kib * 1024), "l2_hit_rate": round(hit / (hit + miss), 3) if hit + miss else None}
             total += kib * 1024
         res[key] = {"streams": streams, "channels": channels, "blocks": blocks, "bytes": int(total), "kernels": kernels,
-                    "source": f"profiles/r02_c_pmc_{tag}.txt"}
-        (ROOT / "profiles" / f"r02_c_pmc_{tag}.txt").write_text((SRC / f"pmc_{tag}.txt").read_text())
+                    "source": f"profiles/{PREFIX}_pmc_{tag}.txt"}
+        (ROOT / "profiles" / f"{PREFIX}_pmc_{tag}.txt").write_text((SRC / f"pmc_{tag}.txt").read_text())
     (ROOT / "profiles" / "traffic.json").write_text(json.dumps(res, indent=1) + "\n")
     for key, v in res.items():
         if key != "_comment":
