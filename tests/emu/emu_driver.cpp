@@ -309,7 +309,7 @@ int main(int argc, char **argv) {
       const unsigned groups = static_cast<unsigned>(channels / cg);
       const unsigned pairs = static_cast<unsigned>(blocks) * streams;
       const unsigned chunk = pairs > 1 ? (pairs + 1) / 2 : pairs;  // exercise the chunked launch (item0 > 0)
-      std::vector<float> scratch(static_cast<size_t>(chunk) * channels * g.B);
+      std::vector<float> scratch(static_cast<size_t>(chunk) * channels * g.P * g.Bp);
       io.scratch = scratch.data();
       io.cg = cg;
       io.groups = channels / cg;
@@ -326,7 +326,8 @@ int main(int argc, char **argv) {
         const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
         const long long planeFloats = (total + 3) / 4 * 4;
         planar.assign(static_cast<size_t>(planeFloats) * channels * streams, 0.0f);
-        const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
+        const int tileFrames = planar_tile_frames(channels);
+        const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
         IoDesc ioP = io;
         ioP.split_planes = splitPlanar ? 1 : 0;
         if (splitPlanar && channels <= 2) {
@@ -334,8 +335,8 @@ int main(int argc, char **argv) {
                             [&]() { planarize_quads_kernel(g, ioP, planar.data(), planeFloats, total); });
         } else {
           miups_emu::launch(static_cast<unsigned>(tiles) * streams, 32,
-                            static_cast<size_t>(channels) * (kPlanarTile + 1) * sizeof(float), true,
-                            [&]() { planarize_kernel(g, ioP, planar.data(), planeFloats, total, tiles); });
+                            static_cast<size_t>(channels) * (tileFrames + 1) * sizeof(float), true,
+                            [&]() { planarize_kernel(g, ioP, planar.data(), planeFloats, total, tiles, tileFrames); });
         }
         ioF.in = planar.data();
         ioF.in_fmt = kF32;

@@ -216,6 +216,10 @@ struct Geometry {
   int n_in;       // input frames per block (B / Lf)
   int B;          // output frames per block
   int hist_frames;  // frames of input history kept per stream = ceil(Oc / S)
+  // pitch of a staging plane in floats: Bc rounded up to a whole number of 128-byte lines, so that every plane (and
+  // every row segment the interleave kernels read) starts on a line boundary (8x / 16x at N = 131072: Bc = 6384 / 3192
+  // floats = 199.5 / 99.75 lines). A channel's P planes take P * Bp floats.
+  int Bp;
 };
 
 // Where samples live for one batched call. Frames are interleaved:

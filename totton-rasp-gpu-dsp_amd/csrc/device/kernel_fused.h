@@ -75,6 +75,9 @@ __device__ unsigned long long mi_stamps[32][8][192];
 #define MI_STAMP(id)
 #endif
 
+#if !defined(MIUPS_ROWS_DEPTH)
+#define MIUPS_ROWS_DEPTH 1  // experiment switch (profiles/): multiplies the frame epilogue's units in flight per thread
+#endif
 #if defined(MIUPS_EXP_SKIP_PAIR_SYNC)  // timing experiment (profiles/r02_d_*): no barrier inside a pair of passes (WRONG results)
 #define MI_SYNC_PAIR() do {} while (0)
 #else
@@ -1126,9 +1129,9 @@ struct FusedKernel {
           for (int e = 0; e < VPT; ++e) {
             const int pp = e / cg, cc = e - pp * cg;
 #if defined(MIUPS_EXP_NT_SCRATCH) && !defined(MIUPS_HOST_EMU)  // experiment switch (profiles/)
-            v[d][e] = __builtin_nontemporal_load(scr + (cc * g.P + q * pg + pp) * g.Bc + i);
+            v[d][e] = __builtin_nontemporal_load(scr + (cc * g.P + q * pg + pp) * g.Bp + i);
 #else
-            v[d][e] = scr[(cc * g.P + q * pg + pp) * g.Bc + i];
+            v[d][e] = scr[(cc * g.P + q * pg + pp) * g.Bp + i];
 #endif
           }
         }
@@ -1170,12 +1173,12 @@ struct FusedKernel {
   template <int FMT, int R>
   static MI_DEVICE void epilogue_rows(const Geometry &g, const IoDesc &io, char *out_blk, const float *scr, int tid) {
     const unsigned Bc = static_cast<unsigned>(g.Bc), cg = static_cast<unsigned>(io.cg), P = static_cast<unsigned>(g.P);
-    constexpr int kDepth = (R >= 16 ? 4 : 8) / (W == 1 ? 2 : 1);
+    constexpr int kDepth = MIUPS_ROWS_DEPTH * (R >= 16 ? 4 : 8) / (W == 1 ? 2 : 1);
     const float *pl[R];  // value e of a unit = (phase e / cg, channel e % cg)
     MI_UNROLL
     for (int e = 0; e < R; ++e) {
       const unsigned pp = static_cast<unsigned>(e) / cg, cc = static_cast<unsigned>(e) - pp * cg;
-      pl[e] = scr + static_cast<size_t>(cc * P + pp) * Bc;
+      pl[e] = scr + static_cast<size_t>(cc * P + pp) * static_cast<unsigned>(g.Bp);
     }
     for (unsigned base = static_cast<unsigned>(tid); base < Bc; base += T * kDepth) {
       float v[kDepth][R];
@@ -1222,7 +1225,7 @@ struct FusedKernel {
     for (long long e = tid; e < total; e += T) {
       const int m = static_cast<int>(e / cg), cc = static_cast<int>(e - static_cast<long long>(m) * cg);
       const int i = m / g.P, p = m - i * g.P;
-      pcm_store(out_blk, FMT, static_cast<long long>(m) * io.channels + cc, scr[(cc * g.P + p) * g.Bc + i]);
+      pcm_store(out_blk, FMT, static_cast<long long>(m) * io.channels + cc, scr[(cc * g.P + p) * g.Bp + i]);
     }
   }
   // Tiled form for many planes (R = cg*P > 16 rows): a [R][64] tile of the staging planes
@@ -1242,7 +1245,7 @@ struct FusedKernel {
       MI_UNROLL
       for (int j = 0; j < EPT; ++j) {
         const int x = tid + j * T, row = x / TI, col = x - row * TI, i = k * TI + col;
-        v[j] = (i < g.Bc) ? scr[static_cast<long long>(row) * g.Bc + i] : 0.0f;
+        v[j] = (i < g.Bc) ? scr[static_cast<long long>(row) * g.Bp + i] : 0.0f;
       }
     };
     fetch(0);
@@ -1310,7 +1313,7 @@ struct FusedKernel {
           MI_UNROLL
           for (int e = 0; e < 4; ++e) {
             const int r = r0 + e, p = r >> lcg, cc = r - (p << lcg);
-            v[d][e] = *reinterpret_cast<const f4 *>(scr + static_cast<long long>(cc * P + p) * g.Bc + 4 * iq);
+            v[d][e] = *reinterpret_cast<const f4 *>(scr + static_cast<long long>(cc * P + p) * g.Bp + 4 * iq);
           }
         }
       }
@@ -1489,7 +1492,7 @@ struct FusedKernel {
         const int p = (pi + rot) % g.P;
         const f4 *gt = ft.GT + static_cast<long long>(p) * 8 * T;
         const f4 *g0 = ft.G0 + p;
-        float *plane = scr_c + static_cast<long long>(p) * g.Bc;
+        float *plane = scr_c + static_cast<long long>(p) * g.Bp;
         int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
         MI_OPAQUE_VGPR(tl);
         phase_inputs_n(tl, Xa, Xb, Wl, gt, g0, V);
@@ -1558,7 +1561,7 @@ struct FusedKernel {
       const int p = (pi + rot) % g.P;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
       const f4 *g0 = ft.G0 + p * 17;
-      float *plane = scr_c + static_cast<long long>(p) * g.Bc;
+      float *plane = scr_c + static_cast<long long>(p) * g.Bp;
       int tl = tid;  // per-phase copy of the thread index (see MI_OPAQUE_VGPR)
       MI_OPAQUE_VGPR(tl);
       phase_inputs(tl, Xa, Xb, Wa, Wa2, Wb, gt, g0, A, B);
@@ -1702,7 +1705,7 @@ struct FusedKernel {
       const int p = ((it >> 1) + rot) % g.P, h = it & 1;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 32 * T;
       const f4 *g0 = ft.G0 + p * (2 * kSelfLanes);
-      float *half = scr_c + static_cast<long long>(p) * g.Bc + h * (g.Bc >> 1);
+      float *half = scr_c + static_cast<long long>(p) * g.Bp + h * (g.Bc >> 1);
       int tl = tid;
       MI_OPAQUE_VGPR(tl);
       int ba = blkA, bb = blkB;
@@ -1779,15 +1782,15 @@ struct FusedKernel {
     const int c0 = (item - sb * io.groups) * io.cg;
     const int s = sb / io.blocks;
     const int blk = sb - s * io.blocks;
-    float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.B;
+    float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.P * g.Bp;
     for (int cc = 0; cc < io.cg; ++cc) {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
       if constexpr (SPLIT) {
-        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc);
       } else {
-        channel_block<EXT>(g, io, b, scr + static_cast<long long>(cc) * g.B, ft, lds, tc, cc);
+        channel_block<EXT>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc);
       }
     }
     MI_STAMP(128);

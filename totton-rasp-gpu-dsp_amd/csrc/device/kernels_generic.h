@@ -166,33 +166,47 @@ MI_GLOBAL void gen_store_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT y, 
 // transpose through LDS ([channel][kPlanarTile + 1] floats), coalesced 256-byte writes
 // per channel. planar[(s*channels + c)*plane_floats + t], t = hist_frames + frame.
 // (reference: the per-channel de-interleave loop, alsa_streamer_main.cpp:315-321)
-constexpr int kPlanarTile = 64;
+constexpr int kPlanarTile = 64;  // smallest tile; planar_tile_frames() picks the size for a channel count
+// frames per workgroup: 8 KiB+ of PCM per workgroup for narrow frames (a 64-frame tile of 8 channels is 2 KiB in, 2 KiB
+// out: the launch ran at 2 TB/s), bounded by the [channels][tile + 1] LDS tile
+MI_HD int planar_tile_frames(int channels) { return channels <= 32 ? 256 : (channels <= 64 ? 128 : 64); }
 MI_GLOBAL void planarize_kernel(Geometry g, IoDesc io, float *MI_RESTRICT planar, long long plane_floats,
-                                long long total_frames, int tiles_per_stream) {
+                                long long total_frames, int tiles_per_stream, int tile_frames) {
   MI_DYN_SHARED(float, tile);
+  const int TF = tile_frames;
   const int s = static_cast<int>(MI_BID_X) / tiles_per_stream;
-  const long long t0 = static_cast<long long>(static_cast<int>(MI_BID_X) - s * tiles_per_stream) * kPlanarTile;
-  const int C = io.channels, n = kPlanarTile * C;
+  const long long t0 = static_cast<long long>(static_cast<int>(MI_BID_X) - s * tiles_per_stream) * TF;
+  const int C = io.channels, n = TF * C;
   const char *hist = static_cast<const char *>(io.hist) + s * io.hist_stream_stride;
   const char *in = static_cast<const char *>(io.in) + s * io.in_stream_stride;
-  for (int e = MI_TID_X; e < n; e += MI_BDIM_X) {
-    const int f = e / C, c = e - f * C;
+  // (frame, channel) of element e = tid + k * threads without a division per element: the kernel is a pure copy and its
+  // index arithmetic was most of its instructions
+  const int bd = MI_BDIM_X, dq = bd / C, dr = bd - dq * C;
+  int f = static_cast<int>(MI_TID_X) / C, c = static_cast<int>(MI_TID_X) - f * C;
+  for (int e = MI_TID_X; e < n; e += bd) {
     const long long t = t0 + f;
     if (t < total_frames) {
       const float v = t < g.hist_frames ? pcm_load(hist, io.in_fmt, t * C + c)
                                         : pcm_load(in, io.in_fmt, (t - g.hist_frames) * C + c);
-      tile[c * (kPlanarTile + 1) + f] = v;
+      tile[c * (TF + 1) + f] = v;
+    }
+    f += dq;
+    c += dr;
+    if (c >= C) {
+      c -= C;
+      ++f;
     }
   }
   MI_SYNC();
-  for (int e = MI_TID_X; e < n; e += MI_BDIM_X) {
-    const int c = e / kPlanarTile, f = e - c * kPlanarTile;
-    const long long t = t0 + f;
+  const int lt = 31 - __builtin_clz(static_cast<unsigned>(TF));  // TF is a power of two
+  for (int e = MI_TID_X; e < n; e += bd) {
+    const int c2 = e >> lt, f2 = e & (TF - 1);
+    const long long t = t0 + f2;
     if (t < total_frames) {
       // io.split_planes: split-planar order (see make_block_io) -- even complex words in the first half of the plane,
       // odd ones in the second
       const long long at = io.split_planes ? ((t & 2) ? (plane_floats >> 1) : 0) + ((t >> 2) << 1) + (t & 1) : t;
-      planar[(static_cast<long long>(s) * C + c) * plane_floats + at] = tile[c * (kPlanarTile + 1) + f];
+      planar[(static_cast<long long>(s) * C + c2) * plane_floats + at] = tile[c2 * (TF + 1) + f2];
     }
   }
 }
@@ -277,7 +291,7 @@ MI_GLOBAL void interleave_quad_kernel(Geometry g, IoDesc io, const float *MI_RES
   const int C = io.channels, P = g.P, Rq = (P * C) >> 2;
   const int units = (g.Bc >> 2) * Rq;
   const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
-  const float *src = planes + static_cast<long long>(jb) * C * g.B;
+  const float *src = planes + static_cast<long long>(jb) * C * g.P * g.Bp;
   char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride + static_cast<long long>(blk) * g.B * C * 4;
   const long long i_step = static_cast<long long>(P) * C * 4;  // bytes from i to i + 1
   const int base = wg * static_cast<int>(MI_BDIM_X) * kUnits + static_cast<int>(MI_TID_X);
@@ -290,7 +304,7 @@ MI_GLOBAL void interleave_quad_kernel(Geometry g, IoDesc io, const float *MI_RES
       MI_UNROLL
       for (int e = 0; e < 4; ++e) {
         const int r = r0 + e, p = r / C, c = r - p * C;
-        const float *pl = src + (static_cast<long long>(c) * P + p) * g.Bc;
+        const float *pl = src + (static_cast<long long>(c) * P + p) * g.Bp;
         if (io.split_planes) {
           // halves of the split form: (y[4m], y[4m+1]) pairs, then (y[4m+2], y[4m+3]) pairs
           const cf lo = *reinterpret_cast<const cf *>(pl + 2 * iq);
@@ -351,7 +365,7 @@ MI_GLOBAL void interleave_tiled_kernel(Geometry g, IoDesc io, const float *MI_RE
   const int C = io.channels, P = g.P, R = P * C, Rq = R >> 2;
   const int i0 = k * TI;
   const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
-  const float *src = planes + static_cast<long long>(jb) * C * g.B;
+  const float *src = planes + static_cast<long long>(jb) * C * g.P * g.Bp;
   char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride + static_cast<long long>(blk) * g.B * C * 4;
   const int tid = MI_TID_X, nt = MI_BDIM_X;
   // EPT = R * Q / threads 16-byte words per thread (host: exact)
@@ -360,7 +374,7 @@ MI_GLOBAL void interleave_tiled_kernel(Geometry g, IoDesc io, const float *MI_RE
   for (int j = 0; j < EPT; ++j) {
     const int x = tid + j * nt, r = x / Q, q4 = (x - r * Q) * 4;
     const int pp = r / C, c = r - pp * C;
-    v[j] = (i0 + q4 < g.Bc) ? *reinterpret_cast<const f4 *>(src + (static_cast<long long>(c) * P + pp) * g.Bc + i0 + q4)
+    v[j] = (i0 + q4 < g.Bc) ? *reinterpret_cast<const f4 *>(src + (static_cast<long long>(c) * P + pp) * g.Bp + i0 + q4)
                             : f4{0.0f, 0.0f, 0.0f, 0.0f};  // Bc % 4 == 0: a word is inside or outside as a whole
   }
   MI_UNROLL
@@ -410,7 +424,7 @@ MI_GLOBAL void interleave_scalar_kernel(Geometry g, IoDesc io, const float *MI_R
   const int i = m / g.P, p = m - i * g.P;
   const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
   const int at = io.split_planes ? ((i & 2) ? (g.Bc >> 1) : 0) + 2 * (i >> 2) + (i & 1) : i;
-  const float val = planes[((static_cast<long long>(jb) * C + c) * g.P + p) * g.Bc + at];
+  const float val = planes[((static_cast<long long>(jb) * C + c) * g.P + p) * g.Bp + at];
   pcm_store(static_cast<char *>(io.out) + s * io.out_stream_stride, io.out_fmt,
             (static_cast<long long>(blk) * g.B + m) * C + c, val);
 }

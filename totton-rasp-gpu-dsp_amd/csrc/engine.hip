@@ -908,7 +908,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     const bool split = filter_->fusedSplit();
     const bool ext = cg_ < channels_ || split;  // the split kernel has no epilogue of its own
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
-    const std::size_t perPair = static_cast<std::size_t>(channels_) * g.B * sizeof(float);
+    const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
     std::size_t budget = static_cast<std::size_t>(1024) << 20;
     if (const char *mb = std::getenv("MIUPS_EXP_CHUNK_MB")) {  // experiment switch (profiles/)
       budget = static_cast<std::size_t>(std::max(1, std::atoi(mb))) << 20;
@@ -979,8 +979,9 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         MI_HIP(hipMalloc(reinterpret_cast<void **>(&planar_), need));
         planarBytes_ = need;
       }
-      const int tiles = static_cast<int>((total + kPlanarTile - 1) / kPlanarTile);
-      const std::size_t lds = static_cast<std::size_t>(channels_) * (kPlanarTile + 1) * sizeof(float);
+      const int tileFrames = planar_tile_frames(channels_);
+      const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
+      const std::size_t lds = static_cast<std::size_t>(channels_) * (tileFrames + 1) * sizeof(float);
       IoDesc ioP = io;
       ioP.split_planes = splitPlanar ? 1 : 0;
       if (splitPlanar && channels_ <= 2) {
@@ -989,7 +990,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
                            planeFloats, total);
       } else {
         hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
-                           planar_, planeFloats, total, tiles);
+                           planar_, planeFloats, total, tiles, tileFrames);
       }
       if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
         return false;

@@ -230,6 +230,7 @@ bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *error
   geo->n_in = static_cast<int>(B / L);
   geo->B = static_cast<int>(B);
   geo->hist_frames = static_cast<int>((static_cast<std::size_t>(geo->Oc) + S - 1) / S);
+  geo->Bp = (geo->Bc + 31) & ~31;
   return true;
 }
 
