@@ -286,6 +286,40 @@ def test_bench_sized_stereo_batch_whole_frame_epilogue(ups, O, gpu, fmt):
     assert np.abs(y[:, 1] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
 
 
+@pytest.mark.parametrize("fname,channels,blocks,switch", [
+    ("filter_48k_16x_80000_min_phase", 8, 4, "MIUPS_EXP_NO_TILED_INTERLEAVE"),  # 128 planes per frame group: tiled vs quad
+    ("filter_48k_8x_80000_min_phase", 12, 3, "MIUPS_EXP_NO_TILED_INTERLEAVE"),  # 96 planes (not a power of two)
+    ("filter_44k_2x_80000_min_phase", 2, 5, "MIUPS_EXP_NO_SPLIT_PLANAR"),       # split form: split-planar timeline vs stereo PCM
+    ("filter_44k_2x_80000_min_phase", 1, 3, "MIUPS_EXP_NO_SPLIT_PLANAR"),       # ... mono
+])
+def test_alternative_data_paths_are_bit_identical(ups, gpu, monkeypatch, fname, channels, blocks, switch):
+    """Two routes for the same numbers: frames assembled by interleave_tiled_kernel or interleave_quad_kernel, and the
+    split form fed from the split-planar timeline (planarize_quads_kernel) or straight from the caller's PCM. Neither
+    changes a single arithmetic operation, so the outputs must agree bit for bit (two calls: the second one starts from
+    carried history)."""
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    filt = ups.Filter(path, device=gpu)
+    rng = np.random.default_rng(channels * 100 + blocks)
+
+    def run():
+        eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+        outs = []
+        for _ in range(2):
+            x = (np.clip(rng_local.standard_normal((blocks * eng.in_frames, channels)) * 0.2, -1, 1) * 2147483647).astype("<i4")
+            outs.append(eng.process_host(x, blocks).copy())
+        return np.concatenate([o.view(np.uint8).reshape(-1) for o in outs])
+
+    rng_local = np.random.default_rng(rng.integers(1 << 30))
+    state = rng_local.bit_generator.state
+    a = run()
+    monkeypatch.setenv(switch, "1")
+    rng_local.bit_generator.state = state
+    b = run()
+    assert a.size == 2 * blocks * filt.config["block_size"] * channels * 4
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a.view("<i4")).max() > 1 << 20  # not silence
+
+
 @pytest.mark.parametrize("channels,blocks,in_off,out_off", [
     (2, 256, 4, 0),    # whole-frame path, input 4-byte aligned only: per-sample loads instead of 16-byte frame pairs
     (2, 256, 0, 4),    # whole-frame path, output 4-byte aligned only: scalar epilogue
