@@ -367,6 +367,21 @@ int main(int argc, char **argv) {
           const int tiles = (g.Bc + tiledTi - 1) / tiledTi;
           EmuInterleaveTiled(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np), tiles, tiledTi,
                              rows * tiledTi / 1024, outFmt == kF32);
+        } else if (quad && (rows == 4 || rows == 8) && !std::getenv("EMU_NO_ROWS_INTERLEAVE")) {
+          const int threads = 32, perWg = threads * (32 / rows);
+          const int wgsPerPair = (g.Bc + perWg - 1) / perWg;
+          auto run = [&](auto kernel) {
+            miups_emu::launch(np * wgsPerPair, threads, 0, false, [&]() {
+              kernel(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+            });
+          };
+          if (outFmt == kF32) {
+            if (rows == 4) run(interleave_rows_kernel<kF32, 4>);
+            else run(interleave_rows_kernel<kF32, 8>);
+          } else {
+            if (rows == 4) run(interleave_rows_kernel<kS32, 4>);
+            else run(interleave_rows_kernel<kS32, 8>);
+          }
         } else if (quad) {
           const int threads = 32, perWg = threads * 4;
           const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels / 4);

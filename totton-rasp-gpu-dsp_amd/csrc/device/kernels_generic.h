@@ -345,6 +345,67 @@ MI_GLOBAL void interleave_quad_kernel(Geometry g, IoDesc io, const float *MI_RES
     }
   }
 }
+// Rows form for few planes (R = P*C = 4 or 8, either plane layout): a lane takes ONE i -- R four-byte loads, one per plane
+// (consecutive lanes read consecutive floats of each plane; in the split layout two 128-byte runs per instruction), and
+// R/4 sixteen-byte stores of whole frame groups (consecutive lanes write consecutive memory: 1 KiB per instruction at
+// R = 4). The quad form's 16-byte loads are lane-contiguous too, but its stores land 64 (128) bytes apart per lane:
+// config 4 (R = 4) 217 us; a variant with eight i per lane 250 us.
+template <int FMT, int R>
+MI_GLOBAL void interleave_rows_kernel(Geometry g, IoDesc io, const float *MI_RESTRICT planes, int sb0, int nb,
+                                      int wgs_per_pair) {
+  constexpr int kDepth = 32 / R;  // 32 loads in flight per lane
+  const int jb = static_cast<int>(MI_BID_X) / wgs_per_pair;
+  if (jb >= nb) {
+    return;
+  }
+  const int wg = static_cast<int>(MI_BID_X) - jb * wgs_per_pair;
+  const unsigned C = static_cast<unsigned>(io.channels), P = static_cast<unsigned>(g.P), Bc = static_cast<unsigned>(g.Bc);
+  const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;
+  const float *src = planes + static_cast<long long>(jb) * C * g.P * g.Bp;
+  char *out_blk = static_cast<char *>(io.out) + s * io.out_stream_stride + static_cast<long long>(blk) * g.B * C * 4;
+  const float *pl[R];  // value e of a frame group = (phase e / C, channel e % C)
+  MI_UNROLL
+  for (int e = 0; e < R; ++e) {
+    const unsigned pp = static_cast<unsigned>(e) / C, c = static_cast<unsigned>(e) - pp * C;
+    pl[e] = src + static_cast<size_t>(c * P + pp) * static_cast<unsigned>(g.Bp);
+  }
+  const unsigned base = static_cast<unsigned>(wg) * MI_BDIM_X * kDepth + MI_TID_X;
+  float v[kDepth][R];
+  MI_UNROLL
+  for (int d = 0; d < kDepth; ++d) {
+    const unsigned i = base + d * MI_BDIM_X;
+    if (i < Bc) {
+      const unsigned at = io.split_planes ? ((i & 2u) ? (Bc >> 1) : 0u) + ((i >> 2) << 1) + (i & 1u) : i;
+      MI_UNROLL
+      for (int e = 0; e < R; ++e) {
+        v[d][e] = pl[e][at];
+      }
+    }
+  }
+  MI_UNROLL
+  for (int d = 0; d < kDepth; ++d) {
+    const unsigned i = base + d * MI_BDIM_X;
+    if (i < Bc) {
+      char *dst = out_blk + static_cast<size_t>(i) * (4 * R);
+      MI_UNROLL
+      for (int e = 0; e < R; e += 4) {
+        if constexpr (FMT == kF32) {
+          *reinterpret_cast<f4 *>(dst + 4 * e) = f4{v[d][e], v[d][e + 1], v[d][e + 2], v[d][e + 3]};
+        } else {
+          struct alignas(16) I4 {
+            int32_t a, b, c, d;
+          };
+          I4 o;
+          o.a = static_cast<int32_t>(pcm_clamp(v[d][e], 0.9999999f) * 2147483648.0f);
+          o.b = static_cast<int32_t>(pcm_clamp(v[d][e + 1], 0.9999999f) * 2147483648.0f);
+          o.c = static_cast<int32_t>(pcm_clamp(v[d][e + 2], 0.9999999f) * 2147483648.0f);
+          o.d = static_cast<int32_t>(pcm_clamp(v[d][e + 3], 0.9999999f) * 2147483648.0f);
+          *reinterpret_cast<I4 *>(dst + 4 * e) = o;
+        }
+      }
+    }
+  }
+}
 // Tiled form for many planes (R = P*C >= 16 rows, plain plane layout): the quad form reads 16 bytes from each of R
 // different planes per wave instruction -- R different cache lines, each revisited by seven later instructions; at
 // R = 128 (config 3) it moved 2.4 TB/s. Here a workgroup takes a tile of TI consecutive i of ALL R rows of one (stream,
@@ -432,25 +493,40 @@ MI_GLOBAL void interleave_scalar_kernel(Geometry g, IoDesc io, const float *MI_R
 // ---- history carry: new_hist = last hist_frames frames of (hist ++ input) --
 // (reference: overlap_.assign(timeBuffer.end() - overlap, ...), :571-572)
 MI_GLOBAL void update_history_kernel(Geometry g, IoDesc io, void *MI_RESTRICT new_hist, long long total_in_frames) {
+  // one 16-byte / 4-byte / 1-byte unit per thread, the widest the row length, the hist/input boundary, the strides and
+  // the bases allow (the byte form alone took 28 us per call for 32 stereo streams of 40 000 frames)
   const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
-  const int bytes = pcm_bytes(io.in_fmt);
-  const long long row_bytes = static_cast<long long>(g.hist_frames) * io.channels * bytes;
-  if (gid >= row_bytes * io.streams) {
+  const long long frame_bytes = static_cast<long long>(io.channels) * pcm_bytes(io.in_fmt);
+  const long long row_bytes = static_cast<long long>(g.hist_frames) * frame_bytes;
+  // bytes of the new row that come from the old one (the rest comes from the end of the input)
+  const long long from_hist = total_in_frames >= g.hist_frames ? 0 : (g.hist_frames - total_in_frames) * frame_bytes;
+  const unsigned long long mix = static_cast<unsigned long long>(row_bytes) | static_cast<unsigned long long>(from_hist) |
+                                 static_cast<unsigned long long>(total_in_frames * frame_bytes) |
+                                 static_cast<unsigned long long>(io.in_stream_stride) |
+                                 static_cast<unsigned long long>(io.hist_stream_stride) |
+                                 reinterpret_cast<uintptr_t>(io.in) | reinterpret_cast<uintptr_t>(io.hist) |
+                                 reinterpret_cast<uintptr_t>(new_hist);
+  const int unit = (mix & 15) == 0 ? 16 : ((mix & 3) == 0 ? 4 : 1);
+  const long long row_units = row_bytes / unit;
+  if (gid >= row_units * io.streams) {
     return;
   }
-  const int s = static_cast<int>(gid / row_bytes);
-  const long long off = gid % row_bytes;
-  const long long frame_bytes = static_cast<long long>(io.channels) * bytes;
-  const long long i = off / frame_bytes;       // frame within new history
-  const long long within = off % frame_bytes;  // byte within frame
-  const long long f = total_in_frames - g.hist_frames + i;
-  unsigned char b;
-  if (f >= 0) {
-    b = static_cast<const unsigned char *>(io.in)[s * io.in_stream_stride + f * frame_bytes + within];
+  const long long s = gid / row_units, off = (gid - s * row_units) * unit;
+  const unsigned char *src =
+      off < from_hist ? static_cast<const unsigned char *>(io.hist) + s * io.hist_stream_stride + (row_bytes - from_hist) + off
+                      : static_cast<const unsigned char *>(io.in) + s * io.in_stream_stride + total_in_frames * frame_bytes -
+                            row_bytes + off;
+  unsigned char *dst = static_cast<unsigned char *>(new_hist) + s * io.hist_stream_stride + off;
+  if (unit == 16) {
+    struct alignas(16) B16 {
+      uint32_t w[4];
+    };
+    *reinterpret_cast<B16 *>(dst) = *reinterpret_cast<const B16 *>(src);
+  } else if (unit == 4) {
+    *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
   } else {
-    b = static_cast<const unsigned char *>(io.hist)[s * io.hist_stream_stride + (g.hist_frames + f) * frame_bytes + within];
+    *dst = *src;
   }
-  static_cast<unsigned char *>(new_hist)[s * io.hist_stream_stride + off] = b;
 }
 
 }  // namespace miups

@@ -1053,6 +1053,22 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
           }
           return false;
         }
+      } else if (quad && (rows == 4 || rows == 8) && std::getenv("MIUPS_EXP_NO_ROWS_INTERLEAVE") == nullptr) {  // experiment switch
+        const int threads = 256, perWg = threads * (32 / rows);  // interleave_rows_kernel: kDepth = 32 / R
+        const int wgsPerPair = (g.Bc + perWg - 1) / perWg;
+        const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
+        const int sb0 = static_cast<int>(p0), nbp = static_cast<int>(np);
+        if (outFmt_ == kF32) {
+          if (rows == 4) {
+            hipLaunchKernelGGL((interleave_rows_kernel<kF32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+          } else {
+            hipLaunchKernelGGL((interleave_rows_kernel<kF32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+          }
+        } else if (rows == 4) {
+          hipLaunchKernelGGL((interleave_rows_kernel<kS32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+        } else {
+          hipLaunchKernelGGL((interleave_rows_kernel<kS32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+        }
       } else if (quad) {
         const int threads = 256, perWg = threads * 4;  // interleave_quad_kernel: kUnits = 4
         const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels_ / 4);
@@ -1117,8 +1133,20 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   // carry the last hist_frames input frames of every stream to the next call
   const long long histBytes = static_cast<long long>(histStride_) * streams_;
   if (histBytes > 0) {
-    hipLaunchKernelGGL(update_history_kernel, dim3(Blocks(histBytes, 256)), dim3(256), 0, st, g, io, hist_[1 - cur_],
-                       static_cast<long long>(blocks) * g.n_in);
+    // threads = copy units; the kernel derives the same unit width (16 / 4 / 1 bytes) from the same quantities
+    const long long totalIn = static_cast<long long>(blocks) * g.n_in;
+    const long long frameBytes = static_cast<long long>(channels_) * pcm_bytes(inFmt_);
+    const long long rowBytes = static_cast<long long>(g.hist_frames) * frameBytes;
+    const long long fromHist = totalIn >= g.hist_frames ? 0 : (g.hist_frames - totalIn) * frameBytes;
+    const unsigned long long mix = static_cast<unsigned long long>(rowBytes) | static_cast<unsigned long long>(fromHist) |
+                                   static_cast<unsigned long long>(totalIn * frameBytes) |
+                                   static_cast<unsigned long long>(io.in_stream_stride) |
+                                   static_cast<unsigned long long>(io.hist_stream_stride) |
+                                   reinterpret_cast<std::uintptr_t>(io.in) | reinterpret_cast<std::uintptr_t>(io.hist) |
+                                   reinterpret_cast<std::uintptr_t>(hist_[1 - cur_]);
+    const int unit = (mix & 15) == 0 ? 16 : ((mix & 3) == 0 ? 4 : 1);
+    hipLaunchKernelGGL(update_history_kernel, dim3(Blocks(rowBytes / unit * streams_, 256)), dim3(256), 0, st, g, io,
+                       hist_[1 - cur_], totalIn);
     if (!HipOk(hipGetLastError(), "update_history_kernel", error)) {
       return false;
     }
