@@ -1062,30 +1062,40 @@ struct FusedKernel {
     // loads fenced ahead of its arithmetic (8 words = 32 registers in flight beside the 128 of the spectrum): see
     // phase_inputs -- left alone the scheduler serialises load, wait, use (19.9k cycles per call instead of ~8k).
     const f4 *pg = gt + tid;
-    f4 gv[2][4];
+#if !defined(MIUPS_PHASE2_SLOTS)
+#define MIUPS_PHASE2_SLOTS 1  // experiment switch (profiles/): slots per table group of the split form's spectral stage
+#endif
+#if !defined(MIUPS_PHASE2_DEPTH)
+#define MIUPS_PHASE2_DEPTH 3  // ... and groups in flight (1x3: 117.9, 2x2: 116.3, 1x2: 110.6 Gsamples/s at config 4)
+#endif
+    constexpr int GS = MIUPS_PHASE2_SLOTS, GD = MIUPS_PHASE2_DEPTH, NG = 16 / GS;
+    f4 gv[GD][2 * GS];
     auto request = [&](int q) {
       MI_UNROLL
-      for (int j = 0; j < 2; ++j) {
-        gv[q & 1][2 * j] = pg[(2 * q + j) * T];
-        gv[q & 1][2 * j + 1] = pg[(16 + 2 * q + j) * T];
+      for (int j = 0; j < GS; ++j) {
+        gv[q % GD][2 * j] = pg[(GS * q + j) * T];
+        gv[q % GD][2 * j + 1] = pg[(16 + GS * q + j) * T];
       }
     };
-    request(0);
     MI_UNROLL
-    for (int q = 0; q < 8; ++q) {
-      if (q < 7) {
-        request(q + 1);
+    for (int q = 0; q < GD - 1; ++q) {
+      request(q);
+    }
+    MI_UNROLL
+    for (int q = 0; q < NG; ++q) {
+      if (q + GD - 1 < NG) {
+        request(q + GD - 1);
       }
       MI_SCHED_FENCE();
       MI_UNROLL
-      for (int j = 0; j < 2; ++j) {
-        const int t = 2 * q + j;
+      for (int j = 0; j < GS; ++j) {
+        const int t = GS * q + j;
         cf ok, om;
 #if defined(MIUPS_EXP_NO_G)  // experiment switch (profiles/): spectral stage without its table words (wrong results)
         quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), f4{1.0f, 0.0f, 1.0f, 0.0f},
                       f4{0.5f, 0.0f, 0.5f, 0.0f}, ok, om);
 #else
-        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), gv[q & 1][2 * j], gv[q & 1][2 * j + 1], ok, om);
+        quad_phase<H>(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), gv[q % GD][2 * j], gv[q % GD][2 * j + 1], ok, om);
 #endif
         if (tid != 0) {
           lds[bA.at(t)] = ok;
