@@ -175,6 +175,12 @@ void mi_debug_fail_next_table_upload(mi_filter *f);
 int mi_engine_enable_kernel_timing(mi_engine *e, int slots);
 double mi_engine_last_kernel_ms(mi_engine *e);
 int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double *max_ms, int *count);
+/* Per kernel class of the latest call (diagnostic, off by default): out4 = ms of [0] planarize, [1] transform,
+ * [2] frame assembly (interleave kernels), [3] history carry; -1 where the call had no such launch. Every launch gets
+ * its own event pair on the stream it runs on, which perturbs the call: use it beside, not inside, a timed region.
+ * Classes that overlap on two streams (pipelined launches) add up to more than the call. */
+int mi_engine_enable_class_timing(mi_engine *e, int on);
+int mi_engine_last_class_ms(mi_engine *e, double *out4);
 
 /* ----------------------------------------------------------------- (2b) --
  * Multi-GPU: independent streams sharded over the GPUs of one node. Stream s runs on slot s mod n_devices; every

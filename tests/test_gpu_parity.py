@@ -320,6 +320,28 @@ def test_alternative_data_paths_are_bit_identical(ups, gpu, monkeypatch, fname, 
     assert np.abs(a.view("<i4")).max() > 1 << 20  # not silence
 
 
+def test_class_timing_reports_the_launches_of_a_call(ups, gpu):
+    """mi_engine_last_class_ms: a wide-frame call has a planarize, a transform, a frame-assembly and a history launch; a
+    stereo call on the whole-frame path has no planarize and no separate frame pass; the output is unchanged by the probes."""
+    path = ROOT / "data" / "coefficients" / "filter_48k_8x_80000_min_phase.json"
+    filt = ups.Filter(path, device=gpu)
+    for channels, expect_none in ((8, ()), (2, ("planarize",))):
+        eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+        blocks = 2 if channels == 8 else 300
+        x = (np.clip(np.random.default_rng(3).standard_normal((blocks * eng.in_frames, channels)) * 0.2, -1, 1) * 2147483647).astype("<i4")
+        plain = eng.process_host(x, blocks).copy()
+        eng.reset()
+        eng.enable_class_timing(True)
+        probed = eng.process_host(x, blocks).copy()
+        ms = eng.last_class_ms()
+        np.testing.assert_array_equal(plain, probed)
+        assert ms["transform"] > 0 and ms["history"] > 0
+        for k in expect_none:
+            assert ms[k] is None
+        if channels == 8:
+            assert ms["planarize"] > 0 and ms["frames"] > 0
+
+
 @pytest.mark.parametrize("channels,blocks,in_off,out_off", [
     (2, 256, 4, 0),    # whole-frame path, input 4-byte aligned only: per-sample loads instead of 16-byte frame pairs
     (2, 256, 0, 4),    # whole-frame path, output 4-byte aligned only: scalar epilogue

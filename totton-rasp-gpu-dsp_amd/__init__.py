@@ -116,6 +116,8 @@ def _load():
         "mi_engine_enable_kernel_timing": (i32, [vp, i32]),
         "mi_engine_last_kernel_ms": (dbl, [vp]),
         "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
+        "mi_engine_enable_class_timing": (i32, [vp, i32]),
+        "mi_engine_last_class_ms": (i32, [vp, f64p]),
         "mi_multi_create": (i32, [cp, i32, C.POINTER(i32), sz, i32, i32, i32, i32, C.POINTER(vp), cp, sz]),
         "mi_multi_destroy": (None, [vp]),
         "mi_multi_set_eq": (i32, [vp, cp, dbl]),
@@ -183,7 +185,7 @@ EXPORTED_SYMBOLS = [
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
     "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_engine_rebind", "mi_filter_generation",
     "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
-    "mi_engine_kernel_ms_stats", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
+    "mi_engine_kernel_ms_stats", "mi_engine_enable_class_timing", "mi_engine_last_class_ms", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
     "mi_multi_process_host", "mi_multi_in_frames_per_block", "mi_multi_out_frames_per_block",
     "mi_multi_device_of_stream", "mi_multi_partition", "mi_bank_load", "mi_bank_release", "mi_bank_size",
     "mi_bank_entry", "mi_bank_select", "mi_rate_family", "mi_same_family", "mi_upsample_ratio", "mi_negotiate",
@@ -392,6 +394,19 @@ class Engine:
 
     def last_kernel_ms(self) -> float:
         return float(lib.mi_engine_last_kernel_ms(self._h))
+
+    def enable_class_timing(self, on: bool = True):
+        """Diagnostic: every launch of the next calls gets its own event pair (perturbs the call)."""
+        if lib.mi_engine_enable_class_timing(self._h, 1 if on else 0) != MI_OK:
+            raise UpsamplerError(last_error())
+
+    def last_class_ms(self) -> dict:
+        """ms per kernel class of the latest call: planarize / transform / frames / history (None = no such launch)."""
+        out = (C.c_double * 4)()
+        if lib.mi_engine_last_class_ms(self._h, out) != MI_OK:
+            raise UpsamplerError(last_error())
+        names = ("planarize", "transform", "frames", "history")
+        return {n: (round(float(v), 5) if v >= 0 else None) for n, v in zip(names, out)}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -478,6 +478,21 @@ int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double 
 
 double mi_engine_last_kernel_ms(mi_engine *e) { return e ? e->engine->LastKernelMs() : -1.0; }
 
+int mi_engine_enable_class_timing(mi_engine *e, int on) {
+  if (!e) {
+    return Fail(MI_ERR_ARG, "null engine");
+  }
+  e->engine->EnableClassTiming(on != 0);
+  return MI_OK;
+}
+
+int mi_engine_last_class_ms(mi_engine *e, double *out4) {
+  if (!e || !out4) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  return e->engine->LastClassMs(out4) ? MI_OK : Fail(MI_ERR_DEVICE, "no class-timed call recorded");
+}
+
 
 // --------------------------------------------------------------- level 2b --
 int mi_multi_create(const char *json_path, int flags, const int *devices, size_t n_devices, int streams, int channels,

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "device/common.h"
@@ -119,6 +120,12 @@ class Engine {
   // their main kernel(s), recorded on the stream the kernels are launched on
   bool EnableTiming(int slots, std::string *error);
   double LastKernelMs();
+  // Per kernel class of the LATEST call: [0] planarize, [1] transform, [2] frame assembly (interleave_*), [3] history
+  // carry -- each launch bracketed by its own event pair on the stream it runs on (so: a diagnostic, the extra event
+  // records perturb the call; classes that overlap on two streams add up to more than the call). -1 where a class has
+  // no launch. Off by default.
+  void EnableClassTiming(bool on) { classTiming_ = on; }
+  bool LastClassMs(double out[4]);
   // average/min/max over the recorded calls since EnableTiming (waits for them)
   bool KernelMsStats(double *avg, double *mn, double *mx, int *count);
   // generation of the filter tables the most recent ProcessDevice call used
@@ -168,6 +175,10 @@ class Engine {
   // [4..5] host input slot copied in, [6..7] its kernels done, [8..9] its output copied out
   void *pipeEv_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long lastGeneration_ = 0;
+  bool classTiming_ = false;
+  std::vector<std::pair<void *, void *>> classEv_[4];  // event pairs of the latest call, per class
+  std::vector<void *> classPool_;
+  bool ClassMark(int cls, void *stream, bool begin);
   // timing
   std::vector<void *> evStart_, evStop_;
   long long evCount_ = 0;

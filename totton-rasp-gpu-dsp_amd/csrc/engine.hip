@@ -596,6 +596,15 @@ Engine::~Engine() {
       (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     }
   }
+  for (auto &v : classEv_) {
+    for (auto &pr : v) {
+      (void)hipEventDestroy(static_cast<hipEvent_t>(pr.first));
+      (void)hipEventDestroy(static_cast<hipEvent_t>(pr.second));
+    }
+  }
+  for (void *e : classPool_) {
+    (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  }
   for (void *e : evStart_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -843,6 +852,50 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   groups_ = channels_ / cg_;
 }
 
+// class timing (diagnostic): begin/end event around one launch on the stream it is enqueued on
+bool Engine::ClassMark(int cls, void *stream, bool begin) {
+  if (!classTiming_) {
+    return true;
+  }
+  hipEvent_t ev = nullptr;
+  if (!classPool_.empty()) {
+    ev = static_cast<hipEvent_t>(classPool_.back());
+    classPool_.pop_back();
+  } else if (hipEventCreate(&ev) != hipSuccess) {
+    return false;
+  }
+  if (hipEventRecord(ev, static_cast<hipStream_t>(stream)) != hipSuccess) {
+    classPool_.push_back(ev);
+    return false;
+  }
+  if (begin) {
+    classEv_[cls].emplace_back(ev, nullptr);
+  } else {
+    classEv_[cls].back().second = ev;
+  }
+  return true;
+}
+
+bool Engine::LastClassMs(double out[4]) {
+  bool any = false;
+  for (int c = 0; c < 4; ++c) {
+    out[c] = -1.0;
+    double sum = 0.0;
+    for (auto &pr : classEv_[c]) {
+      if (!pr.first || !pr.second || hipEventSynchronize(static_cast<hipEvent_t>(pr.second)) != hipSuccess) {
+        continue;
+      }
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, static_cast<hipEvent_t>(pr.first), static_cast<hipEvent_t>(pr.second)) == hipSuccess) {
+        sum += ms;
+        out[c] = sum;
+        any = true;
+      }
+    }
+  }
+  return any;
+}
+
 bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, std::size_t outStride,
                            std::size_t blocks, void *hipStream, std::string *error) {
   if (!dIn || !dOut || blocks == 0) {
@@ -877,6 +930,15 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   hipStream_t st = static_cast<hipStream_t>(hipStream);
   if (!OrderAfterLast(hipStream, error)) {
     return false;
+  }
+  if (classTiming_) {
+    for (auto &v : classEv_) {  // the previous call's pairs go back to the pool
+      for (auto &pr : v) {
+        if (pr.first) classPool_.push_back(pr.first);
+        if (pr.second) classPool_.push_back(pr.second);
+      }
+      v.clear();
+    }
   }
   // the filter tables this call reads: one snapshot for the whole call (an EQ change lands between calls, i.e.
   // between blocks), kept alive until the call's last kernel has finished
@@ -984,6 +1046,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       const std::size_t lds = static_cast<std::size_t>(channels_) * (tileFrames + 1) * sizeof(float);
       IoDesc ioP = io;
       ioP.split_planes = splitPlanar ? 1 : 0;
+      ClassMark(0, st, true);
       if (splitPlanar && channels_ <= 2) {
         const long long quads = (total + 3) / 4 * streams_;
         hipLaunchKernelGGL(planarize_quads_kernel, dim3(Blocks(quads, 256)), dim3(256), 0, st, g, ioP, planar_,
@@ -992,6 +1055,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
                            planar_, planeFloats, total, tiles, tileFrames);
       }
+      ClassMark(0, st, false);
       if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
         return false;
       }
@@ -1018,10 +1082,12 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       ioF.item0 = static_cast<int>(p0 * groups_);
       ioF.scratch = planes;
+      ClassMark(1, st, true);
       if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), static_cast<unsigned>(np * groups_), st,
                          error)) {
         return false;
       }
+      ClassMark(1, st, false);
       if (!ext) {
         continue;
       }
@@ -1032,6 +1098,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         ist = aux;
       }
       // staging planes of this chunk -> interleaved PCM frames
+      ClassMark(2, ist, true);
       const int rows = g.P * channels_;
       int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
       if (quad && !split && rows >= 16 && std::getenv("MIUPS_EXP_NO_TILED_INTERLEAVE") == nullptr) {  // experiment switch
@@ -1086,6 +1153,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, ist, g, ioF, planes,
                            static_cast<int>(p0), static_cast<int>(np));
       }
+      ClassMark(2, ist, false);
       if (!HipOk(hipGetLastError(), "interleave kernel", error)) {
         return false;
       }
@@ -1145,8 +1213,10 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
                                    reinterpret_cast<std::uintptr_t>(io.in) | reinterpret_cast<std::uintptr_t>(io.hist) |
                                    reinterpret_cast<std::uintptr_t>(hist_[1 - cur_]);
     const int unit = (mix & 15) == 0 ? 16 : ((mix & 3) == 0 ? 4 : 1);
+    ClassMark(3, st, true);
     hipLaunchKernelGGL(update_history_kernel, dim3(Blocks(rowBytes / unit * streams_, 256)), dim3(256), 0, st, g, io,
                        hist_[1 - cur_], totalIn);
+    ClassMark(3, st, false);
     if (!HipOk(hipGetLastError(), "update_history_kernel", error)) {
       return false;
     }
