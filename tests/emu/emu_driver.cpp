@@ -330,14 +330,9 @@ int main(int argc, char **argv) {
         const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
         IoDesc ioP = io;
         ioP.split_planes = splitPlanar ? 1 : 0;
-        if (splitPlanar && channels <= 2) {
-          miups_emu::launch(Blocks((total + 3) / 4 * streams, 64), 64, 0, false,
-                            [&]() { planarize_quads_kernel(g, ioP, planar.data(), planeFloats, total); });
-        } else {
-          miups_emu::launch(static_cast<unsigned>(tiles) * streams, 32,
-                            static_cast<size_t>(channels) * (tileFrames + 1) * sizeof(float), true,
-                            [&]() { planarize_kernel(g, ioP, planar.data(), planeFloats, total, tiles, tileFrames); });
-        }
+        miups_emu::launch(static_cast<unsigned>(tiles) * streams, 256,
+                          static_cast<size_t>(channels) * (tileFrames + 1) * sizeof(float), true,
+                          [&]() { planarize_kernel(g, ioP, planar.data(), planeFloats, total, tiles, tileFrames); });
         ioF.in = planar.data();
         ioF.in_fmt = kF32;
         ioF.in_planar = splitPlanar ? 2 : 1;

@@ -294,7 +294,7 @@ def test_bench_sized_stereo_batch_whole_frame_epilogue(ups, O, gpu, fmt):
 ])
 def test_alternative_data_paths_are_bit_identical(ups, gpu, monkeypatch, fname, channels, blocks, switch):
     """Two routes for the same numbers: frames assembled by interleave_tiled_kernel or interleave_quad_kernel, and the
-    split form fed from the split-planar timeline (planarize_quads_kernel) or straight from the caller's PCM. Neither
+    split form fed from the split-planar timeline (planarize_kernel, split_planes) or straight from the caller's PCM. Neither
     changes a single arithmetic operation, so the outputs must agree bit for bit (two calls: the second one starts from
     carried history)."""
     path = ROOT / "data" / "coefficients" / f"{fname}.json"

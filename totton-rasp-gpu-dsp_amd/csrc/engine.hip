@@ -1047,14 +1047,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       IoDesc ioP = io;
       ioP.split_planes = splitPlanar ? 1 : 0;
       ClassMark(0, st, true);
-      if (splitPlanar && channels_ <= 2) {
-        const long long quads = (total + 3) / 4 * streams_;
-        hipLaunchKernelGGL(planarize_quads_kernel, dim3(Blocks(quads, 256)), dim3(256), 0, st, g, ioP, planar_,
-                           planeFloats, total);
-      } else {
-        hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
-                           planar_, planeFloats, total, tiles, tileFrames);
-      }
+      hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
+                         planar_, planeFloats, total, tiles, tileFrames);
       ClassMark(0, st, false);
       if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
         return false;
