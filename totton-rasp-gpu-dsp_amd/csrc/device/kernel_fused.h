@@ -75,6 +75,9 @@ __device__ unsigned long long mi_stamps[32][8][192];
 #define MI_STAMP(id)
 #endif
 
+#if !defined(MIUPS_WIDE_WAVES)
+#define MIUPS_WIDE_WAVES 2  // experiment switch (profiles/): waves per SIMD the wide form is compiled for (3 = 168 registers)
+#endif
 #if !defined(MIUPS_ROWS_DEPTH)
 #define MIUPS_ROWS_DEPTH 1  // experiment switch (profiles/): multiplies the frame epilogue's units in flight per thread
 #endif
@@ -1821,7 +1824,7 @@ struct FusedKernel {
 // SIMD, and a lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5:
 // profiles/r02_a_ubench_valu_lds_rates.txt); the narrow form four waves per SIMD = at most 128 registers.
 template <int LOG2K, bool EXT, int W = 2>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : 2)) void fused_kernel(
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : MIUPS_WIDE_WAVES)) void fused_kernel(
     Geometry g, IoDesc io, FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
   FusedKernel<LOG2K, W>::template run<false, EXT>(g, io, ft, lds);
