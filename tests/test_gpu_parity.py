@@ -191,6 +191,45 @@ def test_wide_frames_match_truth_across_calls(ups, O, gpu, fname, channels, stre
             assert np.abs(y[s, :, c] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max()
 
 
+@pytest.mark.parametrize("fft,taps,L,channels,streams,blocks,fmt_in,fmt_out", [
+    # frame shapes that steer the helper kernels: planes per frame group R = L*channels -> rows (4, 8), quad (12), tiled
+    # (16 .. 512, incl. non powers of two and a partial last tile), scalar (R % 4 != 0); planarize fast path (4-byte input,
+    # whole tiles) and general loop (partial tiles, packed formats)
+    (4096, 1025, 2, 2, 3, 5, "s32", "s32"),     # R = 4: stereo, whole-frame epilogue (rows form inside the kernel), three streams
+    (4096, 1025, 4, 3, 1, 4, "s32", "s32"),     # R = 12: quad form, odd channel count, planar input
+    (8192, 2113, 4, 5, 2, 3, "f32", "f32"),     # R = 20: quad form (20 % 16 != 0), Bc = 1520
+    (8192, 2113, 8, 6, 1, 3, "s32", "f32"),     # R = 48: tiled, three 16-row groups, partial last tile (Bc = 760)
+    (4096, 1025, 16, 12, 1, 2, "s32", "s32"),   # R = 192: tiled with 32-wide tiles
+    (4096, 1025, 16, 32, 1, 2, "f32", "s32"),   # R = 512: tiled with 16-wide tiles
+    (8192, 2049, 2, 7, 1, 3, "s24", "s16"),     # R = 14: scalar interleave, packed input through the general planarize loop
+    (16384, 8193, 2, 2, 2, 3, "s32", "s32"),    # K = 4096, long history (8192 of 16384 samples), two stereo streams
+])
+def test_helper_kernel_shapes_match_truth(ups, O, gpu, make_filter, fft, taps, L, channels, streams, blocks, fmt_in, fmt_out):
+    """Synthetic geometries through every frame-assembly and planarize variant, two calls each (the second starts from
+    carried history), every channel against fp64 truth."""
+    rng = np.random.default_rng(fft + taps + L + channels)
+    h = (rng.standard_normal(taps) * 0.3 / np.sqrt(taps / L)).astype(np.float32)
+    block = fft - (taps - 1)
+    filt = ups.Filter(make_filter(h, fft, block, L), device=gpu)
+    eng = ups.Engine(filt, streams, channels, ups.PCM_NAMES[fmt_in], ups.PCM_NAMES[fmt_out])
+    nin, calls = eng.in_frames, 2
+    xf = np.clip(rng.standard_normal((calls, streams, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    outs, xin = [], []
+    for k in range(calls):
+        raw = xf[k] if fmt_in == "f32" else O.float_to_pcm(xf[k].reshape(-1), fmt_in)
+        xin.append((xf[k].reshape(-1) if fmt_in == "f32" else O.pcm_to_float(raw, fmt_in)).reshape(streams, blocks * nin, channels))
+        out = eng.process_host(raw, blocks)
+        y = out.view(np.float32) if fmt_out == "f32" else O.pcm_to_float(out, fmt_out)
+        outs.append(y.reshape(streams, blocks * block, channels))
+    y = np.concatenate(outs, axis=1)
+    x = np.concatenate(xin, axis=1)
+    lsb = {"f32": 0.0, "s16": 2.0**-15, "s24": 2.0**-23, "s32": 2.0**-31}[fmt_out]
+    for s in range(streams):
+        for c in range(channels):
+            truth = O.truth_stream(x[s, :, c], h.astype(np.float64), L, calls * blocks, block).reshape(-1)
+            assert np.abs(y[s, :, c] - truth).max() <= lsb + TOL_TRUTH * np.abs(truth).max(), (s, c)
+
+
 # ---- float -> PCM on the device: clamp + truncate, bit for bit ---------------------
 def _pcm_case_filter(make_filter, case):
     rng = np.random.default_rng(42)
