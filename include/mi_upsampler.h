@@ -283,6 +283,13 @@ typedef struct mi_runtime_config {
 } mi_runtime_config;
 int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char *err, size_t errcap);
 
+/* One OPRA EQ record (JSON: {"parameters": {"gain_db", "bands": [{"type", "frequency", "gain_db", "q", "slope"}]}, ...})
+ * -> the Equalizer APO text the reference's control plane writes for it (scripts/integration/opra.py:50-244:
+ * convert_opra_to_apo + EqProfile.to_apo_format; modern_target != 0: apply_modern_target_correction, the KB5000_7 band).
+ * The text goes to mi_filter_set_eq / mi_ups_set_eq. Returns MI_OK, MI_ERR_FILTER with a message for malformed JSON,
+ * MI_ERR_ARG when `out` is too small (needed size in *needed, if given). */
+int mi_opra_to_apo(const char *eq_json, int modern_target, char *out, size_t cap, size_t *needed, char *err, size_t errcap);
+
 /* SPSC PCM ring (contract of include/io/audio_ring_buffer.h:23-100, on bytes) -- exported for the tests */
 typedef struct mi_ring mi_ring;
 mi_ring *mi_ring_create(size_t capacity_bytes);

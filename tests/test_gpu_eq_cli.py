@@ -153,6 +153,34 @@ def test_cli_file_mode_matches_engine_and_truth(ups, O, gpu, tmp_path, fmt):
 
 
 @pytest.mark.gpu
+def test_cli_opra_record_equals_the_converted_apo_profile(ups, tmp_path):
+    """--opra record.json [--modern-target] = the OPRA step before the EQ path (reference: web/routers/opra.py:140-160,
+    record -> APO text -> profile file): the output must be byte-identical to --eq with the converted text."""
+    g8 = json.loads((ROOT / "tests" / "golden" / "g8_opra.json").read_text())
+    case = next(c for c in g8["cases"] if c["record"]["name"] == "ten bands")
+    (tmp_path / "record.json").write_text(json.dumps(case["record"]))
+    (tmp_path / "profile.txt").write_text(case["apo_modern_target"])
+    path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+    x = (np.clip(np.random.default_rng(9).standard_normal((30000, 2)) * 0.1, -1, 1) * 2147483647).astype("<i4")
+    (tmp_path / "in.raw").write_bytes(x.tobytes())
+    common = ["--in-file", str(tmp_path / "in.raw"), "--rate", "44100", "--filter", str(path), "--channels", "2", "--format", "s32"]
+    a = subprocess.run([str(BIN), *common, "--out-file", str(tmp_path / "a.raw"), "--opra", str(tmp_path / "record.json"),
+                        "--modern-target"], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([str(BIN), *common, "--out-file", str(tmp_path / "b.raw"), "--eq", str(tmp_path / "profile.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stderr
+    assert b.returncode == 0, b.stderr
+    out_a, out_b = (tmp_path / "a.raw").read_bytes(), (tmp_path / "b.raw").read_bytes()
+    assert len(out_a) == 30000 * 4 * 2 * 4 and out_a == out_b
+    # and the EQ is really in the path: without it the output differs
+    c = subprocess.run([str(BIN), *common, "--out-file", str(tmp_path / "c.raw")], capture_output=True, text=True, timeout=300)
+    assert c.returncode == 0 and (tmp_path / "c.raw").read_bytes() != out_a
+    bad = subprocess.run([str(BIN), *common, "--out-file", str(tmp_path / "d.raw"), "--opra", str(tmp_path / "profile.txt")],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "OPRA: OPRA record:" in bad.stderr
+
+
+@pytest.mark.gpu
 def test_cli_without_filter_is_pcm_passthrough(O, tmp_path):
     x = (np.random.default_rng(1).integers(-2**31, 2**31 - 1, size=4096 * 2, dtype=np.int64)).astype("<i4")
     (tmp_path / "in.raw").write_bytes(x.tobytes())

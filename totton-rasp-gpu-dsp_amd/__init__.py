@@ -116,6 +116,7 @@ def _load():
         "mi_engine_enable_kernel_timing": (i32, [vp, i32]),
         "mi_engine_last_kernel_ms": (dbl, [vp]),
         "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
+        "mi_opra_to_apo": (i32, [C.c_char_p, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
         "mi_engine_enable_class_timing": (i32, [vp, i32]),
         "mi_engine_last_class_ms": (i32, [vp, f64p]),
         "mi_multi_create": (i32, [cp, i32, C.POINTER(i32), sz, i32, i32, i32, i32, C.POINTER(vp), cp, sz]),
@@ -185,7 +186,7 @@ EXPORTED_SYMBOLS = [
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
     "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_engine_rebind", "mi_filter_generation",
     "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
-    "mi_engine_kernel_ms_stats", "mi_engine_enable_class_timing", "mi_engine_last_class_ms", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
+    "mi_engine_kernel_ms_stats", "mi_engine_enable_class_timing", "mi_engine_last_class_ms", "mi_opra_to_apo", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
     "mi_multi_process_host", "mi_multi_in_frames_per_block", "mi_multi_out_frames_per_block",
     "mi_multi_device_of_stream", "mi_multi_partition", "mi_bank_load", "mi_bank_release", "mi_bank_size",
     "mi_bank_entry", "mi_bank_select", "mi_rate_family", "mi_same_family", "mi_upsample_ratio", "mi_negotiate",
@@ -583,6 +584,24 @@ def parse_runtime_config(text: str) -> tuple[bool, str, dict | None]:
     d = {k: (v.decode(errors="replace") if isinstance(v, bytes) else v) for k, v in d.items()}
     d["eq_enabled"] = bool(d["eq_enabled"])
     return True, "", d
+
+
+def opra_to_apo(record, modern_target: bool = False) -> str:
+    """One OPRA EQ record (dict or JSON text) -> Equalizer APO text (reference: scripts/integration/opra.py
+    convert_opra_to_apo(...).to_apo_format(), optionally after apply_modern_target_correction)."""
+    import json as _json
+
+    text = record if isinstance(record, str) else _json.dumps(record)
+    need = C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    out = C.create_string_buffer(4096)
+    rc = lib.mi_opra_to_apo(text.encode(), 1 if modern_target else 0, out, len(out), C.byref(need), err, len(err))
+    if rc == MI_ERR_ARG and need.value > len(out):
+        out = C.create_string_buffer(need.value)
+        rc = lib.mi_opra_to_apo(text.encode(), 1 if modern_target else 0, out, len(out), C.byref(need), err, len(err))
+    if rc != MI_OK:
+        raise UpsamplerError(err.value.decode(errors="replace"))
+    return out.value.decode()
 
 
 def multi_partition(streams: int, slots: int) -> list[int]:

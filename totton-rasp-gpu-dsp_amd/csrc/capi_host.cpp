@@ -13,6 +13,7 @@
 #include "host/filter_config.h"
 #include "host/filter_selector.h"
 #include "host/negotiation.h"
+#include "host/opra.h"
 #include "host/pcm_ring.h"
 #include "host/runtime_config.h"
 #include "host/stream_loop.h"
@@ -333,6 +334,29 @@ int mi_negotiate(int input_rate, int dac_valid, int dac_min_rate, int dac_max_ra
   out->valid = n.valid ? 1 : 0;
   out->requires_reconfiguration = n.requiresReconfiguration ? 1 : 0;
   Put(n.errorMessage, out->error, sizeof(out->error));
+  return MI_OK;
+}
+
+// ---- OPRA record -> APO text ---------------------------------------------------------------------------------
+int mi_opra_to_apo(const char *eq_json, int modern_target, char *out, size_t cap, size_t *needed, char *err, size_t errcap) {
+  if (!eq_json || !out) {
+    Put("null argument", err, errcap);
+    return MI_ERR_ARG;
+  }
+  std::string text, error;
+  if (!miups::OpraToApo(eq_json, modern_target != 0, &text, &error)) {
+    Put(error, err, errcap);
+    return MI_ERR_FILTER;
+  }
+  if (needed) {
+    *needed = text.size() + 1;
+  }
+  if (text.size() + 1 > cap) {
+    Put("output buffer too small", err, errcap);
+    return MI_ERR_ARG;
+  }
+  std::memcpy(out, text.c_str(), text.size() + 1);
+  Put("", err, errcap);
   return MI_OK;
 }
 

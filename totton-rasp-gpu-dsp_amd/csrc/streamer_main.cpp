@@ -15,7 +15,7 @@
 //    streaming loop itself is always built and runs over file endpoints with --loop;
 //  * a non-numeric value of a numeric flag is an error message + exit 1 (the
 //    reference lets std::stoul's exception terminate the process);
-//  * additive flags: --device, --gpus, --streams, --blocks-per-call, --eq, --eq-rate,
+//  * additive flags: --device, --gpus, --streams, --blocks-per-call, --eq, --eq-rate, --opra, --modern-target,
 //    --config, --loop, --drain.
 #include <sys/stat.h>
 
@@ -54,6 +54,8 @@ struct CliOptions {
   unsigned streams = 1;         // file mode: the input file holds this many equal-length streams back to back
   unsigned blocksPerCall = 16;
   std::string eqPath;
+  std::string opraPath;       // one OPRA EQ record (JSON) converted to APO text at start-up
+  bool modernTarget = false;  // ... with the KB5000_7 correction band
   double eqRate = 0.0;
   std::string configPath;       // config.json (eqEnabled / eqProfilePath), re-read on SIGHUP or when it changes
   bool loop = false;            // file endpoints through the streaming loop (period-sized reads)
@@ -86,6 +88,8 @@ void PrintUsage(const char *argv0) {
             << "  --blocks-per-call <n>   Filter blocks batched per GPU call (default: 16)\n"
             << "  --eq <path>             Equalizer-APO profile folded into the filter\n"
             << "  --eq-rate <hz>          Output rate the EQ is evaluated at (default: rate*ratio)\n"
+            << "  --opra <path>           OPRA EQ record (JSON), converted to an Equalizer-APO profile\n"
+            << "  --modern-target         with --opra: add the KB5000_7 correction band\n"
             << "  --config <path>         config.json (eqEnabled, eqProfilePath); re-read on SIGHUP or when it changes\n"
             << "  --loop                  File mode: run the files through the streaming loop in --period reads\n"
             << "  --drain                 With --loop: process the zero-padded tail at end of input and flush\n"
@@ -141,6 +145,8 @@ bool ParseArgs(int argc, char **argv, CliOptions *o) {
     else if (arg == "--streams") ok = number(&o->streams);
     else if (arg == "--blocks-per-call") ok = number(&o->blocksPerCall);
     else if (arg == "--eq") ok = value(&o->eqPath);
+    else if (arg == "--opra") ok = value(&o->opraPath);
+    else if (arg == "--modern-target") o->modernTarget = true;
     else if (arg == "--config") ok = value(&o->configPath);
     else if (arg == "--loop") o->loop = true;
     else if (arg == "--drain") o->drain = true;
@@ -276,6 +282,29 @@ bool PrepareFilter(const CliOptions &o, int fmt, Pipeline *p) {
       return false;
     }
     if (!p->SetEq(text)) {
+      std::cerr << "EQ load failed: " << mi_ups_last_error() << "\n";
+      return false;
+    }
+  }
+  if (!o.opraPath.empty()) {  // reference: web/routers/opra.py:140-160 (record -> APO text -> the EQ path)
+    std::string json;
+    if (!ReadTextFile(o.opraPath, &json)) {
+      std::cerr << "OPRA: Cannot open file: " << o.opraPath << "\n";
+      return false;
+    }
+    std::vector<char> apo(16384);
+    char err[512];
+    size_t need = 0;
+    int rc = mi_opra_to_apo(json.c_str(), o.modernTarget ? 1 : 0, apo.data(), apo.size(), &need, err, sizeof err);
+    if (rc == MI_ERR_ARG && need > apo.size()) {
+      apo.resize(need);
+      rc = mi_opra_to_apo(json.c_str(), o.modernTarget ? 1 : 0, apo.data(), apo.size(), &need, err, sizeof err);
+    }
+    if (rc != MI_OK) {
+      std::cerr << "OPRA: " << err << "\n";
+      return false;
+    }
+    if (!p->SetEq(apo.data())) {
       std::cerr << "EQ load failed: " << mi_ups_last_error() << "\n";
       return false;
     }
