@@ -331,3 +331,22 @@ def test_cli_multi_gpu_file_mode(ups, tmp_path):
     assert len(one) == x.nbytes * 4 and one == (tmp_path / "two.raw").read_bytes()
     r = run_cli([*common, "--out-file", tmp_path / "x.raw", "--gpus", "0,7"])
     assert r.returncode == 1 and "device 7 requested but only" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_null_endpoints_run_the_filter_in_real_time(ups):
+    """The live path without a sound card: silence captured at 44.1 kHz in 1024-frame periods through the 4x filter on the GPU
+    for about a second; the loop must have processed the blocks that fit into that time and stop cleanly on SIGINT."""
+    binary = ROOT / "totton-rasp-gpu-dsp_amd" / "bin" / "alsa_streamer"
+    path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
+    p = subprocess.Popen([str(binary), "--in", "null", "--out", "null", "--rate", "44100", "--period", "1024", "--channels", "2",
+                          "--format", "s32", "--filter", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    time.sleep(4.0)  # filter load + ~0.29 s per 12768-frame block
+    p.send_signal(signal.SIGINT)
+    out, _ = p.communicate(timeout=20)
+    assert p.returncode == 0, out
+    assert "ALSA streaming started: input 44100 Hz, output 176400 Hz, period 1024 frames" in out
+    tail = out.split("ALSA streaming stopped: ")[1]
+    blocks = int(tail.split(" periods, ")[1].split(" blocks")[0])
+    assert blocks >= 2, out
+    assert "overflows 0/0" in tail

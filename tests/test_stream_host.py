@@ -279,3 +279,23 @@ def test_static_stream_partition(ups):
     assert ups.multi_partition(0, 4) == []
     counts = np.bincount(ups.multi_partition(257, 8), minlength=8)
     assert counts.max() - counts.min() == 1
+
+
+# ---- the reference's streamer e2e scenario (tests/cpp/test_alsa_streamer_e2e.cpp:52-140) on the built-in null endpoints ----
+def test_cli_null_endpoints_start_and_stop_on_sigint():
+    """alsa_streamer --in null --out null ... : started log, SIGINT after 200 ms, stopped log, exit code 0 -- the reference
+    test's exact command line and expectations (no filter: PCM pass-through, no GPU involved)."""
+    import signal
+    import time
+
+    binary = ROOT / "totton-rasp-gpu-dsp_amd" / "bin" / "alsa_streamer"
+    assert binary.exists(), "build() must produce bin/alsa_streamer"
+    p = subprocess.Popen([str(binary), "--in", "null", "--out", "null", "--rate", "44100", "--period", "128", "--buffer", "512",
+                          "--channels", "2", "--format", "s32"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    time.sleep(0.2)
+    p.send_signal(signal.SIGINT)
+    out, _ = p.communicate(timeout=3)
+    assert p.returncode == 0, out
+    assert "ALSA streaming started" in out and "ALSA streaming stopped" in out
+    periods = int(out.split("ALSA streaming stopped: ")[1].split(" periods")[0])
+    assert 30 <= periods <= 120  # 200 ms of 128-frame periods at 44.1 kHz is 69: the null capture is paced, not a busy loop

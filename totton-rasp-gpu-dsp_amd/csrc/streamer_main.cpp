@@ -30,6 +30,8 @@
 #include <iterator>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/mi_upsampler.h"
@@ -528,6 +530,27 @@ void BetweenBlocks(void *user) {
 }
 void LogLine(void *, const char *m) { std::cerr << m << "\n"; }
 
+// Built-in "null" endpoints (--in null --out null), the scenario of the reference's tests/cpp/test_alsa_streamer_e2e.cpp
+// without an ALSA library: capture delivers silence at the pace of the sample rate, playback discards.
+struct NullPacer {
+  std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+  unsigned long long frames = 0;
+  unsigned rate = 44100;
+};
+NullPacer gNull;
+long NullRead(void *user, void *dst, size_t frames) {
+  auto *c = static_cast<LoopContext *>(user);
+  std::memset(dst, 0, frames * c->frameBytes);
+  gNull.frames += frames;
+  const auto due = gNull.start + std::chrono::nanoseconds(gNull.frames * 1000000000ull / gNull.rate);
+  while (gRunning && std::chrono::steady_clock::now() < due) {
+    std::this_thread::sleep_for(std::min<std::chrono::nanoseconds>(
+        std::chrono::milliseconds(5), std::chrono::duration_cast<std::chrono::nanoseconds>(due - std::chrono::steady_clock::now())));
+  }
+  return gRunning ? static_cast<long>(frames) : 0;
+}
+int NullWrite(void *, const void *, size_t) { return 1; }
+
 #if defined(HAVE_ALSA)
 // XRUN policy of the reference (alsa_common.cpp:269-336): snd_pcm_recover on -EPIPE / -ESTRPIPE / -EINTR, retry.
 long AlsaRead(void *user, void *dst, size_t frames) {
@@ -633,10 +656,12 @@ int main(int argc, char **argv) {
   std::signal(SIGTERM, OnSignal);
   std::signal(SIGHUP, OnHup);
 
+  const bool nullMode = !fileMode && o.inputDevice == "null" && o.outputDevice == "null";
+  (void)nullMode;
 #if !defined(HAVE_ALSA)
-  if (!fileMode) {
+  if (!fileMode && !nullMode) {
     std::cerr << "ALSA support is not compiled into this build (no alsa-lib headers); "
-                 "use --in-file/--out-file\n";
+                 "use --in-file/--out-file (or --in null --out null)\n";
     return 1;
   }
 #endif
@@ -710,6 +735,17 @@ int main(int argc, char **argv) {
     readFn = FileRead;
     writeFn = FileWrite;
   }
+#if !defined(HAVE_ALSA)
+  else {  // nullMode (checked above)
+    if (inputRate == 0) {
+      inputRate = 44100;
+    }
+    gNull = NullPacer();
+    gNull.rate = inputRate;
+    readFn = NullRead;
+    writeFn = NullWrite;
+  }
+#endif
 #if defined(HAVE_ALSA)
   else {
     if (inputRate == 0) {
