@@ -341,9 +341,18 @@ def test_cli_null_endpoints_run_the_filter_in_real_time(ups):
     path = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
     p = subprocess.Popen([str(binary), "--in", "null", "--out", "null", "--rate", "44100", "--period", "1024", "--channels", "2",
                           "--format", "s32", "--filter", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    time.sleep(4.0)  # filter load + ~0.29 s per 12768-frame block
+    head = ""
+    t0 = time.time()
+    while "ALSA streaming started" not in head and time.time() - t0 < 120:  # device start-up and filter load first
+        line = p.stdout.readline()
+        if not line:
+            break
+        head += line
+    assert "ALSA streaming started" in head, head
+    time.sleep(1.5)  # ~0.29 s per 12768-frame block
     p.send_signal(signal.SIGINT)
-    out, _ = p.communicate(timeout=20)
+    rest, _ = p.communicate(timeout=20)
+    out = head + rest
     assert p.returncode == 0, out
     assert "ALSA streaming started: input 44100 Hz, output 176400 Hz, period 1024 frames" in out
     tail = out.split("ALSA streaming stopped: ")[1]
