@@ -11,7 +11,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 SRC = ROOT / "gpurun_out" / "r02"
-PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02_g"  # profiles/<PREFIX>_pmc_<tag>.txt
+PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02_h"  # profiles/<PREFIX>_pmc_<tag>.txt
 TAGS = {"c2_256": ("2", 1, 2, 256), "c2_2048": ("2_2048blocks", 1, 2, 2048), "c3": ("3", 1, 8, 256), "c4": ("4", 32, 2, 32),
         "c5": ("5", 1, 32, 64)}
 
