@@ -413,7 +413,10 @@ def main() -> int:
 
     if not args.dry_run:
         # BENCH_VISIBLE_DEVICES_FOR_TEST: CPU test hook for the over-subscription check only (tests/test_distributed.py)
-        ndev = int(os.environ.get("BENCH_VISIBLE_DEVICES_FOR_TEST") or ups.device_count())
+        # device_count() is also the first HIP call of the process: the runtime the product library is linked against
+        # initialises here, BEFORE torch (which ships its own ROCm libraries) is imported for the control plane
+        real_ndev = ups.device_count()
+        ndev = int(os.environ.get("BENCH_VISIBLE_DEVICES_FOR_TEST") or real_ndev)
         if ndev < 1:
             print("bench.py: no HIP device (the upsampler has no CPU path)", file=sys.stderr)
             return 1
@@ -477,7 +480,9 @@ def main() -> int:
                   "pcm": "s32 interleaved in/out", "eq": False, "kernel_path": "dry-run"}
     else:
         hip = Hip()
-        device = local_rank
+        # BENCH_STACK_RANKS_FOR_TEST=1 (with BENCH_VISIBLE_DEVICES_FOR_TEST >= ranks): every rank on device 0 -- only to
+        # rehearse the multi-rank code path on a one-GPU box; its numbers mean nothing
+        device = 0 if os.environ.get("BENCH_STACK_RANKS_FOR_TEST") == "1" else local_rank
         hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
         w = Workload(ups, hip, device, args.config, rank, streams, blocks, eq=True if args.eq else None)
         cold = None
@@ -552,6 +557,24 @@ def main() -> int:
                                    "untimed extra steps with one event pair per launch (planarize / transform / frames / history; "
                                    "launches that overlap on two streams add up to more than the call); rocprofv3 --kernel-trace "
                                    "--stats of this command: profiles/r02_*_kernel_stats.csv")
+
+    if not args.dry_run and world > 1 and not args.no_extras and dist is not None:
+        # end to end at N GPUs: every rank drives its own GPU through pinned host buffers at the same time, the
+        # ranks share the node's host links; aggregate = sum over ranks
+        barrier()
+        try:
+            mine = end_to_end(ups, w, seconds=1.5)
+        except Exception as exc:  # every rank still takes part in the gather below
+            mine = {"error": f"{type(exc).__name__}: {exc}"}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if all("value" in r for r in allr):
+            extras["end_to_end"] = dict(allr[0], value=round(sum(r["value"] for r in allr), 3),
+                                        host_link_GB_per_s=round(sum(r["host_link_GB_per_s"] for r in allr), 2),
+                                        per_rank=[r["value"] for r in allr],
+                                        note="sum over ranks, all ranks running at the same time")
+        else:
+            extras["end_to_end"] = {"error": [r.get("error") for r in allr]}
 
     result = {
         "metric": "output Msamples/s, 80k-tap FIR upsample (overlap-save), interleaved s32 PCM in HBM",

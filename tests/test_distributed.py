@@ -135,3 +135,23 @@ def test_stream_partition_and_seeds():
     b = bench.synth_pcm(4, 1, 64, 2)
     assert a.dtype.str == "<i4" and a.shape == (64, 2) and (a != b).any()
     assert (bench.synth_pcm(4, 0, 64, 2) == a).all()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_real_hardware_rehearsal():
+    """The multi-rank bench path with real HIP work, rehearsed on ONE GPU (BENCH_STACK_RANKS_FOR_TEST puts both ranks on
+    device 0; the numbers mean nothing): plain `--gpus 2` spawns its ranks, HIP initialises before torch is imported for the
+    gloo control plane (with the order reversed hipSetDevice finds no device: torch ships its own ROCm libraries), the ranks
+    prime, step and reduce together, and the end-to-end rate is the sum over ranks."""
+    env = dict(os.environ, BENCH_STACK_RANKS_FOR_TEST="1", BENCH_VISIBLE_DEVICES_FOR_TEST="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--prime-seconds", "0.1"], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["streams_total"] == 2 * d["config"]["streams_per_gpu"]
+    assert len(d["end_to_end"]["per_rank"]) == 2 and d["end_to_end"]["value"] > 0
