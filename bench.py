@@ -233,14 +233,17 @@ class Workload:
         self.filt = ups.Filter(self.fpath, device=device)
         self.use_eq = (config_id in (3, 5)) if eq is None else eq
         if self.use_eq:
-            text = json.loads(EQ_PROFILE.read_text())["opra10"]
-            self.filt.set_eq(text, 768000.0 if "48k" in fname else 705600.0)
+            self.eq_text = json.loads(EQ_PROFILE.read_text())["opra10"]
+            self.eq_fs = 768000.0 if "48k" in fname else 705600.0
+            self.filt.set_eq(self.eq_text, self.eq_fs)
         self.eng = ups.Engine(self.filt, self.streams, channels, ups.PCM_S32, ups.PCM_S32)
         self.in_stride, self.out_stride = self.eng.in_bytes(self.blocks), self.eng.out_bytes(self.blocks)
         self.d_in = hip.malloc(self.in_stride * self.streams)
         self.d_out = hip.malloc(self.out_stride * self.streams)
+        self.host_pcm = []  # kept for check_output (the probe blocks' fp64 truth)
         for i, sid in enumerate(stream_ids(rank, self.streams)):
-            hip.h2d(self.d_in + i * self.in_stride, synth_pcm(config_id, sid, self.blocks * self.eng.in_frames, channels))
+            self.host_pcm.append(synth_pcm(config_id, sid, self.blocks * self.eng.in_frames, channels))
+            hip.h2d(self.d_in + i * self.in_stride, self.host_pcm[-1])
         self.stream = hip.stream()
 
     @property
@@ -296,10 +299,50 @@ class Workload:
         self.eng.enable_class_timing(False)
         return {k: round(sum(v) / len(v), 5) for k, v in acc.items()}
 
-    def check_output(self):
-        tail = np.empty(min(self.cfg["block_size"] * self.channels, 65536), dtype="<i4")
-        self.hip.d2h(tail, self.d_out)
-        assert np.abs(tail.astype(np.int64)).max() > 0, "output is all zeros"
+    def truth_block(self, stream_slot: int, channel: int, blk: int, x_stream: np.ndarray) -> np.ndarray:
+        """fp64 statement of one output block of one channel (numpy only, nothing from oracle/): the reference's
+        N-point overlap-save, Y = FFT_N([history | zero-stuffed input]) * FFT_N(h) * EQ, y = Re IFFT_N(Y), keep the
+        last B (vulkan_streaming_upsampler.cpp:528-569). `x_stream` = this stream's PCM frames as float [frames][ch].
+        The history of block `blk` is the O/L frames before it (the engine carries it; blocks >= 2 lie inside the call)."""
+        n, B, L = self.cfg["fft_size"], self.cfg["block_size"], self.cfg["upsample_factor"]
+        O, nin = n - B, B // L
+        h = np.fromfile(self.cfg["coefficients_path"], "<f4").astype(np.float64)
+        H = np.fft.rfft(np.concatenate([h, np.zeros(n - h.size)]))
+        if self.use_eq:
+            import totton_rasp_gpu_dsp_amd as ups
+
+            eq = ups.eq_response_host(self.eq_text, n // 2 + 1, n, self.eq_fs)
+            eq[0], eq[-1] = eq[0].real, eq[-1].real
+            H = H * eq
+        t = np.zeros(n)
+        first = blk * nin - O // L
+        assert first >= 0, "probe block must lie far enough inside the call"
+        t[: O + B : L] = x_stream[first:(blk + 1) * nin, channel]
+        return np.fft.irfft(np.fft.rfft(t) * H, n)[O:]
+
+    def check_output(self, probes=None):
+        """Probe blocks of the output buffer against fp64 truth: 1 LSB + 1e-5 * max|y| (the parity bar of tests/), after the
+        same clamp the PCM store applies. Default probes: last block of (first stream, first channel) and of (last stream,
+        last channel), and a middle block of the last stream's first channel."""
+        B, L = self.cfg["block_size"], self.cfg["upsample_factor"]
+        nin = B // L
+        probes = probes or [(0, 0, self.blocks - 1), (self.streams - 1, self.channels - 1, self.blocks - 1),
+                            (self.streams - 1, 0, max(2, self.blocks // 2))]
+        worst = 0.0
+        for slot, ch, blk in sorted(set(probes)):
+            got = np.empty(B * self.channels, dtype="<i4")
+            self.hip.d2h(got, self.d_out + slot * self.out_stride + blk * B * self.channels * 4)
+            y = got.reshape(B, self.channels)[:, ch].astype(np.float64) / 2147483648.0
+            x = self.host_pcm[slot].astype(np.float64) / 2147483648.0
+            want = np.clip(self.truth_block(slot, ch, blk, x), -1.0, float(np.float32(0.9999999)))
+            err = float(np.abs(y - want).max())
+            tol = 2.0 ** -31 + 1e-5 * float(np.abs(want).max())
+            assert np.abs(want).max() > 1e-3, "truth is silence: bad probe"
+            assert err <= tol, (f"config {self.config_id} stream {slot} channel {ch} block {blk}: max|d| {err:.3e} > {tol:.3e} "
+                                "against fp64 truth")
+            worst = max(worst, err / tol)
+        return {"probes": len(set(probes)), "worst_err_over_tol": round(worst, 4),
+                "bar": "1 LSB + 1e-5*max|y| vs fp64 overlap-save of the same PCM (numpy), after the PCM clamp"}
 
     def close(self):
         self.hip.sync()
@@ -493,7 +536,7 @@ def main() -> int:
             cold = summary(w, args.steps, el, ks, 1, None)
         primed = w.prime(args.prime_seconds) if args.prime_seconds > 0 else 0
         _, elapsed, kstat = w.run(args.steps, args.warmup, barrier)
-        w.check_output()
+        checked = w.check_output()
         units, cfg, cblock = w.units, w.cfg, config_block(w)
 
     elapsed = reduce_max(elapsed)
@@ -537,7 +580,8 @@ def main() -> int:
             _, el, ks = wl.run(args.steps, args.warmup)
             s = summary(wl, args.steps, el, ks, 1, traffic)
             variants[f"blocks_{LONG_BLOCKS}"] = {"blocks_per_channel": LONG_BLOCKS, "value": s["value"],
-                                                 "ms_per_step": s["ms_per_step"], "roofline": s["roofline"]}
+                                                 "ms_per_step": s["ms_per_step"], "roofline": s["roofline"],
+                                                 "output_check": wl.check_output()}
             wl.close()
         extras["variants"] = variants
         extras["end_to_end"] = end_to_end(ups, w)
@@ -549,7 +593,8 @@ def main() -> int:
             _, el, ks = wc.run(args.steps, args.warmup)
             s = summary(wc, args.steps, el, ks, 1, traffic)
             rows.append({"id": cid, "config": config_block(wc), "value": s["value"], "unit": "Msamples/s",
-                         "ms_per_step": s["ms_per_step"], "roofline": s["roofline"], "per_kernel_ms": wc.per_kernel_ms()})
+                         "ms_per_step": s["ms_per_step"], "roofline": s["roofline"], "output_check": wc.check_output(),
+                         "per_kernel_ms": wc.per_kernel_ms()})
             if wc is not w:
                 wc.close()
         extras["configs"] = rows
@@ -596,6 +641,7 @@ def main() -> int:
                               "launching stream, max over ranks"),
     }
     if not args.dry_run:
+        result["output_check"] = checked
         result["priming"] = {"seconds": args.prime_seconds, "calls": primed,
                              "what": "untimed run of the headline call before the W warmup steps (device clocks); "
                                      "0 disables, variants.cold_start is the measurement without it"}

@@ -222,6 +222,33 @@ def test_filter_bank_resident_filters_and_rebind(ups, O, gpu):
     np.testing.assert_array_equal(np.concatenate([a, b]), y4.view(np.uint8).reshape(-1))
 
 
+@pytest.mark.parametrize("small,large", [
+    ((64, 17, 3), (4096, 1025, 3)),    # both non power-of-two ratios (P = 1): K = 32 -> K = 2048
+    ((32, 9, 8), (8192, 2049, 3)),     # K = 2 with P = 8 -> K = 4096 with P = 1: transform length AND phase count change
+    ((4096, 1025, 3), (64, 17, 3)),    # and back down
+])
+def test_rebind_on_the_staged_path_resizes_its_work_buffers(ups, O, gpu, make_filter, small, large):
+    """The staged (any-size) path keeps items x K x (1 | P) complex words of work buffers. An engine rebound to a filter
+    with a longer transform and called with the SAME item count must get buffers of the new size (round-2 advisor
+    finding: EnsureWork compared item counts only -- a device out-of-bounds write). Both filters against fp64 truth."""
+    rng = np.random.default_rng(sum(small) + sum(large))
+    filters = []
+    for k, (fft, taps, L) in enumerate((small, large)):
+        h = (rng.standard_normal(taps) * 0.3 / np.sqrt(taps / L)).astype(np.float32)
+        filters.append((h, fft - taps + 1, L, ups.Filter(make_filter(h, fft, fft - taps + 1, L, name=f"rb{k}"), device=gpu)))
+    eng = ups.Engine(filters[0][3], 2, 2, ups.PCM_F32, ups.PCM_F32)
+    blocks = 3
+    for h, block, L, filt in filters:   # first pass on filter 0 as created, then the rebind
+        if filt is not eng.filter:
+            eng.rebind(filt, reset_history=True)
+        assert eng.path == "staged"
+        x = real_input(block + L, 2 * blocks * eng.in_frames * 2).reshape(2, blocks * eng.in_frames, 2)
+        y = eng.process_host(x, blocks).view(np.float32).reshape(2, blocks * block, 2)
+        for s in range(2):
+            for c in range(2):
+                assert rel_err(y[s, :, c], O.truth_stream(x[s, :, c], h, L, blocks, block).reshape(-1)) <= 1e-5
+
+
 # ---- the streaming loop through the CLI ----------------------------------------------------------------------------
 def run_cli(args, timeout=300):
     return subprocess.run([str(BIN), *map(str, args)], capture_output=True, text=True, timeout=timeout)

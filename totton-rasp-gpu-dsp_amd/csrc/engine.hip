@@ -789,19 +789,37 @@ bool Engine::Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std
     return false;
   }
   const Geometry &g = filter->geometry();
+  const Geometry &old = filter_->geometry();
   const std::size_t stride = static_cast<std::size_t>(g.hist_frames) * channels_ * pcm_bytes(inFmt_);
   const bool sameHistory = stride == histStride_;
   // the history is raw input frames: it stays valid under another filter of the same history length
   if (!sameHistory) {
-    Reap(true);  // buffers of the old size are about to be freed
+    // new buffers first: a failed allocation leaves the engine exactly as it was (old filter, old history)
     const std::size_t bytes = std::max<std::size_t>(stride * streams_, 16);
+    void *fresh[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+      if (!HipOk(hipMalloc(&fresh[i], bytes), "hipMalloc(history)", error)) {
+        (void)hipFree(fresh[0]);
+        return false;
+      }
+    }
+    Reap(true);  // buffers of the old size are about to be freed
     for (int i = 0; i < 2; ++i) {
       (void)hipFree(hist_[i]);
-      hist_[i] = nullptr;
-      MI_HIP(hipMalloc(&hist_[i], bytes));
+      hist_[i] = fresh[i];
     }
     histStride_ = stride;
     cur_ = 0;
+  }
+  if (g.K != old.K || g.P != old.P) {
+    // the staged path's work buffers are sized items * K * (1 | P) complex words: a filter with another transform
+    // length or phase count must not find buffers counted in the old filter's items (EnsureWork compares item counts)
+    Reap(true);
+    for (auto *&w : work_) {
+      (void)hipFree(w);
+      w = nullptr;
+    }
+    workItems_ = 0;
   }
   filter_ = std::move(filter);
   fused_ = filter_->hasFused() && FusedCovers(g, channels_, inFmt_, outFmt_);
