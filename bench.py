@@ -5,7 +5,8 @@
 
 With N > 1 and no launcher the script starts N fresh child processes itself (one rank per GPU, before anything
 touches HIP in the parent); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it
-uses the ranks the launcher made. Either way a run with more ranks than visible devices fails loudly.
+uses the ranks the launcher made (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment). Either way a run with
+more ranks than visible devices fails loudly.
 
 A *step* = one pass of the hot path over one batch of synthetic PCM that is already resident in HBM:
 `mi_engine_process_device` on interleaved s32 frames (PCM load -> FFT -> spectral multiply -> P inverse FFTs ->
@@ -14,8 +15,10 @@ overlap-discard -> PCM store, plus the small history-carry kernel).
 Workload at N = 1 is BASELINE.json configs[1]: 44.1k -> 176.4k (4x), stereo, 80 001-tap minimum-phase filter, 256 blocks
 per channel per launch as BASELINE.md section 4 states it. The path shards by independent streams: with N
 ranks every rank runs its own stream(s) of the same size on its own GPU -- no data-path collective -- so the scaling is
-*weak*; torch.distributed (gloo) is used only for the rendezvous, the barriers around the timed region and the
-max-over-ranks of the elapsed and kernel times.
+*weak* (`--split channels`: the channels of the SAME streams in N contiguous groups, *strong* scaling -- BASELINE
+configs[4]'s 32-channel sweep). The control plane (rendezvous, the barriers around the timed region, max-over-ranks of the
+elapsed and kernel times) is a standard-library Unix-socket hub on rank 0 (class Control): torch is not imported, so one
+HIP runtime is mapped per process (`hip_runtimes_mapped` in the line).
 
 ONE JSON line on rank 0. Besides the contract's fields:
   roofline      ALGORITHMIC bytes (4B(1+1/L) per channel-block + the filter half-spectrum once per launch)
@@ -23,7 +26,10 @@ ONE JSON line on rank 0. Besides the contract's fields:
                 = HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json)
   variants      the same workload at 2048 blocks per launch, and a ~2 s sustained run of the headline launch
   configs       BASELINE configs[1..4] (ids 2-5), each with value / ms / kernel ms / roofline (N = 1 only)
-  end_to_end    PCIe-inclusive rate of mi_engine_process_host on pinned host buffers (H2D, kernels, D2H overlapped)
+  end_to_end    PCIe-inclusive rate of mi_engine_process_host on pinned host buffers (H2D, kernels, D2H overlapped);
+                end_to_end_by_output_format: the same with s16 / packed-s24 output; process_block_latency: p50 / p99 of the
+                reference-shaped one-channel-block call (mi_ups_process_block)
+  roofline.copy_ceiling_GBps   measured device-to-device copy rate of this box, and the fraction against it
   cpu_baseline  the reference's own C++ (oracle/_ref) -- or the C restatement when that library is absent -- on one
                 core AND on all cores of this host (one channel per process), plus the config-1 scipy.signal.fftconvolve
                 leg (stereo 8192-frame block, zero-stuffed 2x, 80 001 taps)
@@ -220,10 +226,14 @@ def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
 class Workload:
     """One config resident on this rank's GPU: filter (+EQ), engine, synthetic PCM in HBM."""
 
-    def __init__(self, ups, hip, device, config_id, rank, streams=None, blocks=None, eq=None):
+    def __init__(self, ups, hip, device, config_id, rank, streams=None, blocks=None, eq=None, channel_slice=None):
+        """channel_slice = (first, count): this GPU takes that contiguous channel group of every stream (--split channels);
+        the synthetic frames are the full-width ones, cut -- every channel sees the samples it sees on one GPU."""
         fname, s, channels, b, desc = CONFIGS[config_id]
         self.config_id, self.desc, self.fname = config_id, desc, fname
-        self.streams, self.channels, self.blocks = streams or s, channels, blocks or b
+        c0, nch = channel_slice or (0, channels)
+        self.full_channels = channels
+        self.streams, self.channels, self.blocks = streams or s, nch, blocks or b
         self.fpath = ROOT / "data" / "coefficients" / fname
         ok, msg, cfg = ups.read_filter(self.fpath)
         if not ok:
@@ -236,13 +246,14 @@ class Workload:
             self.eq_text = json.loads(EQ_PROFILE.read_text())["opra10"]
             self.eq_fs = 768000.0 if "48k" in fname else 705600.0
             self.filt.set_eq(self.eq_text, self.eq_fs)
-        self.eng = ups.Engine(self.filt, self.streams, channels, ups.PCM_S32, ups.PCM_S32)
+        self.eng = ups.Engine(self.filt, self.streams, nch, ups.PCM_S32, ups.PCM_S32)
         self.in_stride, self.out_stride = self.eng.in_bytes(self.blocks), self.eng.out_bytes(self.blocks)
         self.d_in = hip.malloc(self.in_stride * self.streams)
         self.d_out = hip.malloc(self.out_stride * self.streams)
         self.host_pcm = []  # kept for check_output (the probe blocks' fp64 truth)
         for i, sid in enumerate(stream_ids(rank, self.streams)):
-            self.host_pcm.append(synth_pcm(config_id, sid, self.blocks * self.eng.in_frames, channels))
+            full = synth_pcm(config_id, sid, self.blocks * self.eng.in_frames, channels)
+            self.host_pcm.append(np.ascontiguousarray(full[:, c0:c0 + nch]))
             hip.h2d(self.d_in + i * self.in_stride, self.host_pcm[-1])
         self.stream = hip.stream()
 
@@ -401,6 +412,73 @@ def end_to_end(ups, w: Workload, seconds=2.0) -> dict:
     return res
 
 
+def end_to_end_format(ups, w: Workload, fmt: str, seconds=1.0) -> dict:
+    """The same host-buffer call with s32 in and a narrower PCM format out (s16 / packed s24): the D2H side carries 2 or 3
+    bytes per sample instead of 4, and the host link is what bounds the end-to-end rate."""
+    out_fmt = ups.PCM_NAMES[fmt]
+    eng = ups.Engine(w.filt, w.streams, w.channels, ups.PCM_S32, out_fmt)
+    pin_in = ups.PinnedBuffer(eng.in_bytes(w.blocks) * w.streams)
+    pin_out = ups.PinnedBuffer(eng.out_bytes(w.blocks) * w.streams)
+    pin_in.array[:] = np.concatenate([x.reshape(-1) for x in w.host_pcm]).view(np.uint8)
+    for _ in range(2):
+        eng.process_host(pin_in.array, w.blocks, out=pin_out.array)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or n < 3:
+        eng.process_host(pin_in.array, w.blocks, out=pin_out.array)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    host_bytes = pin_in.array.nbytes + pin_out.array.nbytes
+    res = {"value": round(w.units * w.cfg["block_size"] / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(dt * 1e3, 4),
+           "host_link_GB_per_s": round(host_bytes / dt / 1e9, 2), "host_bytes_per_call": int(host_bytes), "pcm": f"s32 in, {fmt} out"}
+    pin_in.close()
+    pin_out.close()
+    eng.close()
+    return res
+
+
+def process_block_latency(ups, device, filter_path, calls=1000) -> dict:
+    """The reference's own call shape (vulkan_streaming_upsampler.h:33, callers alsa_streamer_main.cpp:321,543): ONE block
+    of ONE channel per call through mi_ups_process_block -- host float in, H2D, kernels, D2H, host float out, blocking."""
+    u = ups.StreamingUpsampler(device)
+    ok, msg = u.load_filter(filter_path)
+    if not ok:
+        raise RuntimeError(msg)
+    cfg = u.config
+    nin = cfg["block_size"] // cfg["upsample_factor"]
+    x = (np.random.default_rng(5).standard_normal(nin) * 0.2).astype(np.float32)
+    out = np.empty(cfg["block_size"], dtype=np.float32)
+    fx, fo = x.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float))
+    for _ in range(20):
+        assert ups.lib.mi_ups_process_block(u._h, fx, nin, fo, out.size) == out.size
+    t = np.empty(calls)
+    for i in range(calls):
+        t0 = time.perf_counter()
+        ups.lib.mi_ups_process_block(u._h, fx, nin, fo, out.size)
+        t[i] = time.perf_counter() - t0
+    u.close()
+    ms = np.sort(t) * 1e3
+    return {"calls": calls, "p50_ms": round(float(ms[calls // 2]), 4), "p99_ms": round(float(ms[int(calls * 0.99)]), 4),
+            "mean_ms": round(float(ms.mean()), 4), "Msamples_per_s_at_p50": round(cfg["block_size"] / ms[calls // 2] / 1e3, 2),
+            "block_audio_ms_at_output_rate": round(cfg["block_size"] / (44100.0 * cfg["upsample_factor"]) * 1e3, 2),
+            "what": "mi_ups_process_block, one channel-block per call (host float in/out, blocking), headline filter"}
+
+
+def copy_ceiling(ups, device) -> dict:
+    return {"read_plus_write_GBps": ups.device_copy_rate(device, 1 << 30, 5)}
+
+
+def hip_runtimes_mapped() -> list:
+    """Distinct libamdhip64 images in this process (must be exactly one: the one the product library links)."""
+    seen = set()
+    try:
+        for line in Path("/proc/self/maps").read_text().splitlines():
+            if "libamdhip64" in line:
+                seen.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(seen)
+
+
 # ----------------------------------------------------------------------------------------------------- launching --
 def free_port() -> int:
     with socket.socket() as s:
@@ -408,19 +486,131 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+class Control:
+    """Control plane of an N-rank run on ONE node: rendezvous, barriers, max / sum reductions and an all-gather of small
+    JSON objects. Rank 0 is the hub on a Unix-domain socket whose path is derived from MASTER_ADDR/MASTER_PORT (the same
+    variables torchrun sets; the port itself is never bound here, so a launcher's own store on it is not disturbed).
+    Standard library only: no second HIP runtime enters the process (torch ships its own ROCm libraries; round 2's
+    gloo control plane needed an import-order rule because of it). Every wait has a deadline: a rank that dies takes the
+    others down with an error instead of leaving them in a rendezvous."""
+
+    def __init__(self, rank: int, world: int, timeout: float = 120.0):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.peers, self.sock = [], None
+        if world == 1:
+            return
+        key = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}_{os.environ.get('MASTER_PORT', '0')}_{world}"
+        self.path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"miups_bench_{key}.sock".replace("/", "_"))
+        deadline = time.monotonic() + timeout
+        if rank == 0:
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(self.path)
+            srv.listen(world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            try:
+                while len(by_rank) < world - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    hello = self._recv(conn)
+                    if hello.get("world") != world or not 0 < hello.get("rank", 0) < world or hello["rank"] in by_rank:
+                        conn.close()
+                        raise RuntimeError(f"control plane: unexpected peer {hello}")
+                    by_rank[hello["rank"]] = conn
+            finally:
+                srv.close()
+                try:
+                    os.unlink(self.path)
+                except FileNotFoundError:
+                    pass
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            while True:
+                s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    s.connect(self.path)
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    s.close()
+                    if time.monotonic() > deadline:
+                        raise RuntimeError(f"control plane: rank 0 did not open {self.path} within {timeout:.0f} s")
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            self.sock = s
+            self._send(s, {"rank": rank, "world": world})
+
+    @staticmethod
+    def _send(sock, obj):
+        data = json.dumps(obj).encode()
+        sock.sendall(len(data).to_bytes(8, "little") + data)
+
+    @staticmethod
+    def _recv(sock):
+        def exact(n):
+            buf = b""
+            while len(buf) < n:
+                part = sock.recv(n - len(buf))
+                if not part:
+                    raise RuntimeError("control plane: a peer closed its connection (did a rank fail?)")
+                buf += part
+            return buf
+        return json.loads(exact(int.from_bytes(exact(8), "little")).decode())
+
+    def all_gather(self, obj) -> list:
+        """Everyone contributes one JSON-serialisable object and gets the list of all of them, in rank order."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            parts = [obj] + [self._recv(c) for c in self.peers]
+            for c in self.peers:
+                self._send(c, parts)
+            return parts
+        self._send(self.sock, obj)
+        return self._recv(self.sock)
+
+    def barrier(self):
+        self.all_gather(None)
+
+    def reduce_max(self, v: float) -> float:
+        return max(self.all_gather(float(v)))
+
+    def reduce_sum(self, v: float) -> float:
+        return sum(self.all_gather(float(v)))
+
+    def close(self):
+        for c in self.peers + ([self.sock] if self.sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no launcher: N children, one rank each, rendezvous on 127.0.0.1. The parent
-    touches neither HIP nor torch; rank 0's stdout (the ONE json line) is the parent's."""
+    touches no HIP; rank 0's stdout (the ONE json line) is the parent's. The first child that fails ends the others:
+    nobody is left waiting in a rendezvous or a barrier."""
     port = free_port()
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("GLOO_SOCKET_IFNAME", "lo")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+                for q in live:  # exact PIDs of our own children
+                    q.terminate()
     return rc
 
 
@@ -432,6 +622,9 @@ def main() -> int:
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="headline workload (default: configs[1])")
     ap.add_argument("--blocks", type=int, default=0, help="override blocks per channel")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--split", choices=("streams", "channels"), default="streams",
+                    help="how N > 1 GPUs share the work: independent streams per GPU (weak scaling, default) or contiguous "
+                         "channel groups of the SAME streams (strong scaling: BASELINE configs[4] '32-channel, 1->8 GPU sweep')")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no variants / configs / end_to_end")
@@ -444,20 +637,17 @@ def main() -> int:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "RANK" not in os.environ and args.gpus > 1:
-        return spawn_ranks(args.gpus)  # nothing below has run yet in this process: no HIP, no torch
+        return spawn_ranks(args.gpus)  # nothing below has run yet in this process: no HIP
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
 
-    # product library first: it brings in the HIP runtime it was built against
     import totton_rasp_gpu_dsp_amd as ups
 
     if not args.dry_run:
         # BENCH_VISIBLE_DEVICES_FOR_TEST: CPU test hook for the over-subscription check only (tests/test_distributed.py)
-        # device_count() is also the first HIP call of the process: the runtime the product library is linked against
-        # initialises here, BEFORE torch (which ships its own ROCm libraries) is imported for the control plane
         real_ndev = ups.device_count()
         ndev = int(os.environ.get("BENCH_VISIBLE_DEVICES_FOR_TEST") or real_ndev)
         if ndev < 1:
@@ -468,55 +658,50 @@ def main() -> int:
             print(f"bench.py: {world} ranks requested but only {ndev} HIP device(s) are visible; ranks are never "
                   "stacked on one GPU", file=sys.stderr)
             return 3
+    fname, streams, channels, blocks, desc = CONFIGS[args.config]
+    streams = args.streams or streams
+    blocks = args.blocks or blocks
+    by_channels = args.split == "channels" and world > 1
+    if by_channels and channels % world:
+        print(f"bench.py: --split channels needs the channel count ({channels}) to be a multiple of --gpus ({world})",
+              file=sys.stderr)
+        return 2
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist  # control plane only (gloo): rendezvous, barriers, max-reduce
+    ctl = Control(rank, world)
+    try:
+        return run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, blocks, desc, by_channels)
+    except Exception:
+        # a failing rank closes its control connection on the way out: its peers' next wait raises instead of hanging
+        import traceback
 
-        # gloo reports its connection state on stdout; keep stdout for the ONE json line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        traceback.print_exc()
+        return 1
+    finally:
+        ctl.close()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
 
-    def reduce_max(v: float) -> float:
-        if dist is None:
-            return v
-        t = torch.tensor([v], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
+def run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, blocks, desc, by_channels) -> int:
     try:
         traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text())
     except (OSError, ValueError):
         traffic = {}
-
-    fname, streams, channels, blocks, desc = CONFIGS[args.config]
-    streams = args.streams or streams
-    blocks = args.blocks or blocks
+    # this rank's share: its own streams (all channels), or channels [c0, c0 + nch) of the job's streams
+    nch = channels // world if by_channels else channels
+    c0 = rank * nch if by_channels else 0
     extras = {}
+    if os.environ.get("BENCH_FAIL_RANK_FOR_TEST") == str(rank):  # CPU test hook: a rank that dies after the rendezvous
+        raise RuntimeError(f"rank {rank}: failure injected by BENCH_FAIL_RANK_FOR_TEST")
     if args.dry_run:
         ok, msg, cfg = ups.read_filter(ROOT / "data" / "coefficients" / fname)
         if not ok:
             print(f"bench.py: {msg}", file=sys.stderr)
             return 1
-        barrier()
+        ctl.barrier()
         elapsed = 0.010 * (rank + 1)  # deterministic, rank-dependent: the max-reduce must pick the last rank
-        barrier()
+        ctl.barrier()
         kavg = elapsed * 1e3 / max(args.steps, 1)
         kstat = {"avg": kavg, "min": 0.0, "count": 0}
-        units = blocks * streams * channels
+        units = blocks * streams * nch
         cblock = {"workload": f"configs[{args.config - 1}]: {desc}", "filter": fname, "taps": cfg["taps"],
                   "fft_size": cfg["fft_size"], "block_size": cfg["block_size"], "upsample_factor": cfg["upsample_factor"],
                   "streams_per_gpu": streams, "channels": channels, "blocks_per_channel": blocks,
@@ -527,7 +712,8 @@ def main() -> int:
         # rehearse the multi-rank code path on a one-GPU box; its numbers mean nothing
         device = 0 if os.environ.get("BENCH_STACK_RANKS_FOR_TEST") == "1" else local_rank
         hip.check(hip.lib.hipSetDevice(device), "hipSetDevice")
-        w = Workload(ups, hip, device, args.config, rank, streams, blocks, eq=True if args.eq else None)
+        w = Workload(ups, hip, device, args.config, 0 if by_channels else rank, streams, blocks, eq=True if args.eq else None,
+                     channel_slice=(c0, nch) if by_channels else None)
         cold = None
         if world == 1 and not args.no_extras and args.prime_seconds > 0:
             # the contract's W + K steps on a device that has just been idle (data synthesis, uploads): reported beside the
@@ -535,20 +721,19 @@ def main() -> int:
             _, el, ks = w.run(args.steps, args.warmup)
             cold = summary(w, args.steps, el, ks, 1, None)
         primed = w.prime(args.prime_seconds) if args.prime_seconds > 0 else 0
-        _, elapsed, kstat = w.run(args.steps, args.warmup, barrier)
+        _, elapsed, kstat = w.run(args.steps, args.warmup, ctl.barrier)
         checked = w.check_output()
         units, cfg, cblock = w.units, w.cfg, config_block(w)
+        cblock["channels"] = channels
 
-    elapsed = reduce_max(elapsed)
-    kstat = dict(kstat, avg=reduce_max(kstat["avg"]))  # the slowest rank's kernels price the roofline
-    owned = stream_ids(rank, streams)
-    if dist is not None:
-        ids = [None] * world
-        dist.all_gather_object(ids, owned)
-        all_ids = sorted(i for part in ids for i in part)
-    else:
-        all_ids = owned
-    assert all_ids == list(range(world * streams)), "stream partition must be disjoint and complete"
+    elapsed = ctl.reduce_max(elapsed)
+    kstat = dict(kstat, avg=ctl.reduce_max(kstat["avg"]))  # the slowest rank's kernels price the roofline
+    # the partition must be disjoint and complete: (stream, channel) units over all ranks
+    owned = [[sid, c] for sid in stream_ids(0 if by_channels else rank, streams) for c in range(c0, c0 + nch)]
+    all_units = sorted(tuple(u) for part in ctl.all_gather(owned) for u in part)
+    total_streams = streams if by_channels else world * streams
+    assert all_units == [(sid, c) for sid in range(total_streams) for c in range(channels)], \
+        "the (stream, channel) partition must be disjoint and complete"
 
     if args.dry_run:
         samples = units * cfg["block_size"] * world * args.steps
@@ -561,6 +746,12 @@ def main() -> int:
                              "algorithmic_bytes_per_launch": int(bytes_launch)}}
     else:
         head = summary(w, args.steps, elapsed, kstat, world, traffic)
+        # measured device-to-device copy ceiling of THIS box beside the 8 TB/s spec figure
+        ceil = ctl.reduce_max(-copy_ceiling(ups, device)["read_plus_write_GBps"])  # min over ranks
+        head["roofline"]["copy_ceiling_GBps"] = round(-ceil, 1)
+        head["roofline"]["frac_of_copy_ceiling"] = round(head["roofline"]["achieved"] / -ceil, 5)
+        head["roofline"]["copy_ceiling_what"] = ("mi_device_copy_rate: 16-byte-per-lane grid-stride copy kernel, 1 GiB, bytes "
+                                                 "read + bytes written over the hipEvent time, best of 5 (min over ranks)")
 
     if not args.dry_run and world == 1 and not args.no_extras:
         # the same workload as 8 rounds of workgroups per launch, and a sustained run of the headline launch
@@ -585,6 +776,11 @@ def main() -> int:
             wl.close()
         extras["variants"] = variants
         extras["end_to_end"] = end_to_end(ups, w)
+        # what a caller with 16-bit / packed 24-bit output gets: fewer bytes per sample over the host link (D2H dominates)
+        extras["end_to_end_by_output_format"] = {
+            fmt: end_to_end_format(ups, w, fmt) for fmt in ("s16", "s24")}
+        # the drop-in call itself: one block of one channel per call through the reference-shaped handle
+        extras["process_block_latency"] = process_block_latency(ups, device, w.fpath)
         rows = []
         for cid in sorted(CONFIGS):
             wc = w if cid == args.config and not (args.blocks or args.streams) else Workload(ups, hip, device, cid, rank)
@@ -592,6 +788,7 @@ def main() -> int:
                 wc.prime(args.prime_seconds)
             _, el, ks = wc.run(args.steps, args.warmup)
             s = summary(wc, args.steps, el, ks, 1, traffic)
+            s["roofline"]["frac_of_copy_ceiling"] = round(s["roofline"]["achieved"] / head["roofline"]["copy_ceiling_GBps"], 5)
             rows.append({"id": cid, "config": config_block(wc), "value": s["value"], "unit": "Msamples/s",
                          "ms_per_step": s["ms_per_step"], "roofline": s["roofline"], "output_check": wc.check_output(),
                          "per_kernel_ms": wc.per_kernel_ms()})
@@ -601,18 +798,17 @@ def main() -> int:
         extras["per_kernel_ms"] = ("roofline.kernel_ms_* = one hipEvent pair around all kernels of a call; configs[].per_kernel_ms = "
                                    "untimed extra steps with one event pair per launch (planarize / transform / frames / history; "
                                    "launches that overlap on two streams add up to more than the call); rocprofv3 --kernel-trace "
-                                   "--stats of this command: profiles/r02_*_kernel_stats.csv")
+                                   "--stats, one CSV per config: profiles/r03_*_kernel_stats_config*.csv")
 
-    if not args.dry_run and world > 1 and not args.no_extras and dist is not None:
+    if not args.dry_run and world > 1 and not args.no_extras:
         # end to end at N GPUs: every rank drives its own GPU through pinned host buffers at the same time, the
         # ranks share the node's host links; aggregate = sum over ranks
-        barrier()
+        ctl.barrier()
         try:
             mine = end_to_end(ups, w, seconds=1.5)
         except Exception as exc:  # every rank still takes part in the gather below
             mine = {"error": f"{type(exc).__name__}: {exc}"}
-        allr = [None] * world
-        dist.all_gather_object(allr, mine)
+        allr = ctl.all_gather(mine)
         if all("value" in r for r in allr):
             extras["end_to_end"] = dict(allr[0], value=round(sum(r["value"] for r in allr), 3),
                                         host_link_GB_per_s=round(sum(r["host_link_GB_per_s"] for r in allr), 2),
@@ -621,6 +817,11 @@ def main() -> int:
         else:
             extras["end_to_end"] = {"error": [r.get("error") for r in allr]}
 
+    if by_channels:
+        par = (f"channels of the same {channels}-channel stream(s) split into {world} contiguous groups of {nch}, one group "
+               "per GPU, no collective")
+    else:
+        par = f"streams sharded over {world} GPU(s), no collective"
     result = {
         "metric": "output Msamples/s, 80k-tap FIR upsample (overlap-save), interleaved s32 PCM in HBM",
         "value": head["value"],
@@ -630,12 +831,12 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if by_channels else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": dict(cblock, streams_total=world * streams,
-                       parallelism=f"streams sharded over {world} GPU(s), no collective"),
+        "config": dict(cblock, streams_total=total_streams, channels_per_gpu=nch, parallelism=par,
+                       control_plane="unix-socket hub on this node (stdlib); no torch, one HIP runtime per process"),
         "roofline": dict(head["roofline"],
                          note="bytes = units*4B(1+1/L) + 8(N/2+1); duration = hipEvent pair around the call's kernels on the "
                               "launching stream, max over ranks"),
@@ -645,14 +846,13 @@ def main() -> int:
         result["priming"] = {"seconds": args.prime_seconds, "calls": primed,
                              "what": "untimed run of the headline call before the W warmup steps (device clocks); "
                                      "0 disables, variants.cold_start is the measurement without it"}
+        result["hip_runtimes_mapped"] = hip_runtimes_mapped()
     result.update(extras)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             result["cpu_baseline"] = cpu_baseline(ROOT / "data" / "coefficients" / fname, args.cpu_seconds)
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctl.barrier()
     return 0
 
 

@@ -148,6 +148,13 @@ int mi_engine_process_host(mi_engine *e, const void *h_in, size_t in_stream_stri
 /* pinned host memory for the buffers of mi_engine_process_host (hipHostMalloc / hipHostFree) */
 void *mi_host_alloc(size_t bytes);
 void mi_host_free(void *p);
+/* ... or pin a buffer the caller already owns (hipHostRegister / hipHostUnregister): do it ONCE for a buffer that is
+ * passed to mi_engine_process_host / mi_multi_process_host again and again; unregister before freeing it */
+int mi_host_register(void *p, size_t bytes);
+void mi_host_unregister(void *p);
+/* measured device-to-device copy rate of `device`, GB/s counting bytes read + bytes written (16-byte-per-lane copy
+ * kernel over `bytes` per buffer, best of `iters`): the bench line's copy ceiling beside the HBM spec peak */
+int mi_device_copy_rate(int device, size_t bytes, int iters, double *gbps);
 
 /* Stream contract of an engine: every call is ordered after the previous call on the same engine, whatever streams
  * the two calls used (the engine chains them with events), so history and staging buffers never race. An engine is
@@ -183,12 +190,22 @@ int mi_engine_enable_class_timing(mi_engine *e, int on);
 int mi_engine_last_class_ms(mi_engine *e, double *out4);
 
 /* ----------------------------------------------------------------- (2b) --
- * Multi-GPU: independent streams sharded over the GPUs of one node. Stream s runs on slot s mod n_devices; every
- * slot owns a device, its own filter tables, histories, HIP streams, pinned staging and one host worker thread. No
- * data is exchanged between devices (reference: channels are independent objects, alsa_streamer_main.cpp:248-250,
- * 537-553). A device may be listed twice (two slots on one GPU). Creation fails with a message when a
- * listed device is not visible.
+ * Multi-GPU: the independent units of the path sharded over the GPUs of one node. Two partitions:
+ *   default                    stream s runs on slot s mod n_devices (many independent streams);
+ *   MI_MULTI_SPLIT_CHANNELS    (OR it into `flags`) the channels of EVERY stream are cut into n_devices contiguous groups,
+ *                              group i = channels [i C / n, (i+1) C / n) on slot i: ONE wide stream over several GPUs. Each
+ *                              slot moves its column group straight out of / into the caller's interleaved frames with
+ *                              pitched 2-D copies: no host de-interleave, each device's link carries only its channels.
+ * Every slot owns a device, its own filter tables, histories, HIP streams, staging and one host worker thread pinned to
+ * the CPUs local to its device (sysfs local_cpulist). No data is exchanged between devices (reference: channels are
+ * independent objects, alsa_streamer_main.cpp:247-250,536-553). A device may be listed twice (two slots on
+ * one GPU). Creation fails with a message when a listed device is not visible.
+ * Host buffers: pageable memory works at the runtime's staging speed; use mi_host_alloc memory, or pin your own buffer
+ * ONCE with mi_host_register, for buffers that are passed again and again.
+ * mi_multi_set_eq is all-or-nothing: every slot's new tables are built first and published together; when one build
+ * fails no slot changes.
  */
+#define MI_MULTI_SPLIT_CHANNELS 0x10000
 typedef struct mi_multi mi_multi;
 int mi_multi_create(const char *json_path, int flags, const int *devices, size_t n_devices, int streams, int channels,
                     int in_fmt, int out_fmt, mi_multi **out, char *err, size_t errcap);
@@ -201,6 +218,13 @@ int mi_multi_process_host(mi_multi *m, const void *h_in, size_t in_stream_stride
 size_t mi_multi_in_frames_per_block(const mi_multi *m);
 size_t mi_multi_out_frames_per_block(const mi_multi *m);
 int mi_multi_device_of_stream(const mi_multi *m, int stream);
+int mi_multi_device_of_channel(const mi_multi *m, int channel);
+/* the channel partition itself (pure): first_channel_of_slot has slots + 1 entries, group i = [f[i], f[i+1]) */
+int mi_multi_partition_channels(int channels, int slots, int *first_channel_of_slot);
+/* the CPU list slot's worker thread is pinned to ("" = platform gave none, or none of them is allowed to this process) */
+int mi_multi_worker_cpus(const mi_multi *m, int slot, char *out, size_t cap);
+/* test hook: the next mi_multi_set_eq fails while building slot `slot`'s tables */
+void mi_debug_multi_fail_next_eq_on_slot(mi_multi *m, int slot);
 /* the partition itself (pure): slot_of_stream[s] = s mod slots */
 int mi_multi_partition(int streams, int slots, int *slot_of_stream);
 
@@ -314,10 +338,13 @@ typedef struct mi_loop_params {
   int format;
   size_t period_frames, block_in_frames, block_out_frames, max_blocks_per_call;
   int drain_at_end; /* additive: process the zero-padded tail and flush (the reference stops at the first short read) */
+  int pinned_rings; /* additive: the two staging rings live in mi_host_alloc memory, and a batch that does not wrap a
+                     * ring's end is handed to `process` IN PLACE (no bounce copy; DMA-able by mi_engine_process_host) */
 } mi_loop_params;
 typedef struct mi_loop_stats {
   size_t periods_read, blocks_processed, frames_written, silence_frames_written, input_overflows, output_overflows,
       process_calls;
+  size_t in_place_calls; /* process calls whose input and output were both contiguous pieces of the rings */
 } mi_loop_stats;
 int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn write, mi_process_fn process,
                        mi_between_fn between, mi_log_fn log, void *user, const volatile int *running,
@@ -328,10 +355,14 @@ int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn wri
  * freedom and the mirror pairing without a GPU:
  *   mi_lds_swizzle        LDS word index -> physical word index
  *   mi_fused_set_of_block sixteen-bin set {a + t*K/16} held by LDS block b after the forward FFT
- *   mi_fused_block_a      first LDS block of thread tau in the two passes next to the spectral stage */
+ *   mi_fused_block_a      first LDS block of thread tau in the two passes next to the spectral stage
+ *   mi_fused_plan_radices the pass plan itself */
 int mi_lds_swizzle(int word_index);
 int mi_fused_set_of_block(int block, int log2k);
 int mi_fused_block_a(int tau, int log2k);
+/* radices of the in-LDS passes, forward order (2^(log2k mod 4), 16, .., 16); returns the pass count, -1 when out is
+ * too small */
+int mi_fused_plan_radices(int log2k, int *out, size_t cap);
 
 /* Load-time tables as the kernels will see them (host build, for inspection):
  * geometry[10] = log2k,K,M,P,S,Oc,Bc,n_in,B,hist_frames; which: 0 Gs, 1 Gc,

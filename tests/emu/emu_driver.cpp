@@ -145,11 +145,21 @@ void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsign
       return;
     }
   }
-  using Cfg = FusedCfg<LOG2K>;
+  using Cfg = FusedCfg<LOG2K, 2, false>;
+  if constexpr (fused_plan_r32_exists(LOG2K, 2)) {
+    if (t.fusedR32) {  // radix-32 pass plan (experiment, EMU_R32)
+      if (io.ext_epilogue) {
+        miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 2, true>(g, io, ft); });
+      } else {
+        miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 2, true>(g, io, ft); });
+      }
+      return;
+    }
+  }
   if (io.ext_epilogue) {
-    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true>(g, io, ft); });
+    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 2, false>(g, io, ft); });
   } else {
-    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false>(g, io, ft); });
+    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 2, false>(g, io, ft); });
   }
 }
 
@@ -236,6 +246,9 @@ int main(int argc, char **argv) {
   }
   if (std::getenv("EMU_NARROW")) {  // tests: one butterfly per thread (experiment form) where it exists
     flags |= kLoadInternalNarrow;
+  }
+  if (std::getenv("EMU_R32")) {  // tests: the radix-32 pass plan (experiment) at K = 8192 / 16384
+    flags |= kLoadInternalR32;
   }
   const int streams = std::atoi(argv[3]), channels = std::atoi(argv[4]);
   const int inFmt = std::atoi(argv[5]), outFmt = std::atoi(argv[6]);

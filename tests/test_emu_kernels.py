@@ -51,6 +51,22 @@ CASES = [
     (4096, 1025, 2, "fused", 1, 8, 1, 2),  # 8 channels: planar input, one channel per workgroup, interleave kernel
     (4096, 1025, 8, "fused", 1, 12, 2, 1),  # 12 channels
     (8192, 2049, 1, "fused", 1, 1, 1, 2),  # K = 4096 (radices 16,16,16)
+    (16384, 4097, 1, "fused", 1, 2, 1, 2),  # K = 8192 = 2 * 16^3, stereo, whole-frame epilogue
+    (32768, 8193, 1, "fused", 1, 1, 1, 1),  # K = 16384 = 4 * 16^3
+]
+PRUNED_CASES = [  # history >= half the transform (O/N >= 1/2, like every shipped filter): pruned last inverse pass
+    (1024, 641, 1, "fused", 1, 2, 2, 2),    # K = 512 = 2 * 16^2: radix-2 last pass
+    (2048, 1281, 1, "fused", 1, 1, 2, 2),   # K = 1024 = 4 * 16^2: radix 4
+    (1024, 641, 4, "fused", 1, 2, 2, 2),    # K = 128 = 8 * 16: radix 8, four phases
+    (512, 321, 1, "fused", 2, 2, 2, 2),     # K = 256 = 16^2: radix 16, two butterflies per thread
+    (8192, 5121, 1, "fused", 1, 1, 1, 2),   # K = 4096 = 16^3 (the 16x geometry's transform length)
+    (1024, 642, 1, "fused", 1, 1, 2, 2),    # odd history length: the unpruned scalar plane path stays in charge
+]
+R32_CASES = [  # the radix-32 pass plan (experiment switch MIUPS_EXP_R32; kernel_fused.h FusedCfg)
+    (16384, 4097, 1, "fused", 1, 2, 1, 2),  # K = 8192: passes 16, 32, 16
+    (65536, 16385, 4, "fused", 1, 1, 2, 1),  # K = 8192 with four phases
+    (32768, 8193, 1, "fused", 1, 1, 1, 2),  # K = 16384: passes 32, 32, 16
+    (32768, 8192, 1, "fused", 1, 2, 1, 1),  # K = 16384, odd history length (plane_write without the even-Oc fast path)
 ]
 NARROW_CASES = [
     (2048, 600, 1, 1, 2, 2, 2),   # K = 1024 = 4*16*16: one wave
@@ -80,6 +96,18 @@ def test_emulated_narrow_form(emu, O, make_filter, tmp_path, monkeypatch, fft, t
             truth = O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1)
             got = np.concatenate([y[k, s_, :, c] for k in range(calls)])
             assert np.abs(got - truth).max() <= 1e-5 * np.abs(truth).max()
+
+
+@pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", PRUNED_CASES)
+def test_emulated_pruned_last_pass(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls):
+    test_emulated_kernels_match_truth(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls)
+
+
+@pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", R32_CASES)
+def test_emulated_radix32_plan(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, path, streams, channels, blocks,
+                               calls):
+    monkeypatch.setenv("EMU_R32", "1")
+    test_emulated_kernels_match_truth(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls)
 
 
 @pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", CASES)
@@ -245,6 +273,10 @@ def test_emulated_wide_epilogue(emu, O, make_filter, tmp_path, monkeypatch, fft,
     (16384, 4097, 1, 1, 1, "f32", "s32"),   # half length 4096 (radices 16,16,16)
     (32768, 8193, 4, 1, 1, "f32", "f32"),   # half length 2048, four phases
     (32768, 8193, 1, 1, 2, "s32", "f32"),   # half length 8192 (radices 2,16,16,16): 256 threads
+    # history >= half the transform (like the shipped 2x filters): pruned last inverse pass of every half transform
+    (4096, 2561, 1, 1, 1, "f32", "f32"),    # half length 1024, radix-4 last pass
+    (16384, 10241, 2, 1, 2, "s32", "s32"),  # half length 2048, radix 8, two phases, stereo
+    (32768, 20481, 1, 1, 1, "f32", "f32"),  # half length 8192, radix 2
 ])
 def test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, streams, channels, in_fmt, out_fmt):
     """fused_split_kernel: the block transform is twice the LDS transform length (the product

@@ -54,6 +54,64 @@ def test_multi_engine_is_bit_identical_to_one_engine(ups, gpu, devices, streams)
     np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
 
 
+@pytest.mark.parametrize("fname,channels,devices,streams,fmt", [
+    ("filter_48k_8x_160000_linear_phase", 32, [0, 0], 1, "s32"),        # BASELINE configs[4]: 32 channels over 2 ...
+    ("filter_48k_8x_160000_linear_phase", 32, [0, 0, 0, 0], 1, "s32"),  # ... and over 4 slots (8 channels each)
+    ("filter_44k_4x_80000_min_phase", 6, [0, 0, 0, 0], 2, "s24"),       # uneven groups 1, 2, 1, 2; two streams; packed 24 bit
+    ("filter_44k_4x_80000_min_phase", 2, [0, 0, 0], 1, "s16"),          # more slots than channels: one slot stays empty
+])
+def test_channel_split_is_bit_identical_to_one_engine(ups, gpu, fname, channels, devices, streams, fmt):
+    """MI_MULTI_SPLIT_CHANNELS: contiguous channel groups of the SAME stream(s) on several slots, each slot moving its
+    column group out of / into the caller's interleaved frames with pitched copies. Channels are independent units
+    (alsa_streamer_main.cpp:247-250,536-553): whatever the grouping, the bytes must be those of one engine over the whole
+    frame -- across two calls (carried history per slot) and after a reset."""
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    pcm = ups.PCM_NAMES[fmt]
+    filt = ups.Filter(path, device=gpu)
+    one = ups.Engine(filt, streams, channels, pcm, pcm)
+    multi = ups.MultiEngine(path, devices, streams, channels, pcm, pcm, split_channels=True)
+    groups = ups.multi_partition_channels(channels, len(devices))
+    assert groups[0] == 0 and groups[-1] == channels and all(b >= a for a, b in zip(groups, groups[1:]))
+    assert [multi.device_of_channel(c) for c in range(channels)] == [0] * channels
+    blocks = 2
+    nbytes = one.in_bytes(blocks) * streams
+    for k in range(2):
+        x = np.random.default_rng(40 + k).integers(0, 256, nbytes, dtype=np.uint8)
+        if fmt != "s16":   # keep the levels moderate: top byte of every sample small
+            b = ups.PCM_BYTES[pcm]
+            x.reshape(-1, b)[:, b - 1] = (x.reshape(-1, b)[:, b - 1].astype(np.int8) >> 3).view(np.uint8)
+        np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+    multi.reset()
+    one.reset()
+    np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+    # a buffer the caller owns, pinned in place once (mi_host_register): same bytes
+    reg = ups.RegisteredBuffer(x.copy())
+    multi.reset()
+    one.reset()
+    np.testing.assert_array_equal(multi.process_host(reg.array, blocks), one.process_host(x, blocks))
+    reg.close()
+    for slot in range(len(devices)):
+        assert isinstance(multi.worker_cpus(slot), str)   # "" where the platform gives no local_cpulist
+
+
+def test_multi_engine_eq_change_is_all_or_nothing(ups, gpu):
+    """mi_multi_set_eq builds every slot's tables first and publishes them together: a failure on slot 1 must leave slot 0
+    on the OLD spectrum too (round-2 advisor finding: slots before the failing one had already switched)."""
+    streams, channels, blocks = 2, 2, 2
+    multi = ups.MultiEngine(F4X, [0, 0], streams, channels)
+    x = synth(streams, blocks * multi.in_frames, channels, seed=5)
+    plain = multi.process_host(x, blocks).copy()
+    ups.lib.mi_debug_multi_fail_next_eq_on_slot(multi._h, 1)
+    with pytest.raises(ups.UpsamplerError, match="no slot was changed"):
+        multi.set_eq(PROFILES["opra10"], 705600.0)
+    multi.reset()
+    np.testing.assert_array_equal(multi.process_host(x, blocks), plain)      # both streams still on the plain filter
+    multi.set_eq(PROFILES["opra10"], 705600.0)                                # and the next change goes through everywhere
+    multi.reset()
+    eqd = multi.process_host(x, blocks).reshape(streams, -1)
+    assert all((eqd[s] != plain.reshape(streams, -1)[s]).any() for s in range(streams))
+
+
 def test_multi_engine_refuses_devices_that_are_not_there(ups, gpu):
     n = ups.device_count()
     with pytest.raises(ups.UpsamplerError, match=f"device {n} requested but only {n} HIP device"):

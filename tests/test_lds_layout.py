@@ -12,9 +12,6 @@ import pytest
 from conftest import GOLDEN
 
 
-def radices(m):
-    return ([1 << (m % 4)] if m % 4 else []) + [16] * (m // 4)
-
 
 def extra_cycles(words, group, nbanks):
     """words: LDS word (8-byte) index per lane of one wave instruction. Returns the
@@ -33,13 +30,14 @@ def pass_words(ups, m, tables):
     """Yield, per pass, the list of per-wave-instruction lane address lists."""
     K = 1 << m
     J, T = K // 16, K // 32
-    rad = radices(m)
+    rad = ups.fused_plan_radices(m)  # 2^(m mod 4), 16, .., 16
+    assert np.prod(rad) == K and rad[-1] == 16
     block_b = tables["blockB"]
     L = K
     for pi, R in enumerate(rad):
         S = L // R
         last = pi == len(rad) - 1
-        per_thread = (K // R) // T
+        per_thread = max((K // R) // T, 1)
         instrs = []
         for w0 in range(0, T, 64):
             lanes = range(w0, min(w0 + 64, T))

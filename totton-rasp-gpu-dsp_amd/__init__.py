@@ -30,6 +30,7 @@ PCM_F32, PCM_S16, PCM_S24_3LE, PCM_S32 = 0, 1, 2, 3
 PCM_NAMES = {"f32": PCM_F32, "s16": PCM_S16, "s24": PCM_S24_3LE, "s32": PCM_S32}
 PCM_BYTES = {PCM_F32: 4, PCM_S16: 2, PCM_S24_3LE: 3, PCM_S32: 4}
 LOAD_DEFAULT, LOAD_REF_COMPAT_SPECTRUM = 0, 1
+MULTI_SPLIT_CHANNELS = 0x10000
 MI_OK, MI_ERR_ARG, MI_ERR_FILTER, MI_ERR_DEVICE, MI_ERR_SIZE = range(5)
 
 
@@ -53,12 +54,12 @@ class _RuntimeConfig(C.Structure):
 class _LoopParams(C.Structure):
     _fields_ = [("channels", C.c_uint), ("format", C.c_int), ("period_frames", C.c_size_t),
                 ("block_in_frames", C.c_size_t), ("block_out_frames", C.c_size_t), ("max_blocks_per_call", C.c_size_t),
-                ("drain_at_end", C.c_int)]
+                ("drain_at_end", C.c_int), ("pinned_rings", C.c_int)]
 
 
 class _LoopStats(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("periods_read", "blocks_processed", "frames_written", "silence_frames_written",
-                                          "input_overflows", "output_overflows", "process_calls")]
+                                          "input_overflows", "output_overflows", "process_calls", "in_place_calls")]
 
 
 READ_FN = C.CFUNCTYPE(C.c_long, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -109,6 +110,9 @@ def _load():
         "mi_engine_process_host": (i32, [vp, vp, sz, vp, sz, sz]),
         "mi_host_alloc": (vp, [sz]),
         "mi_host_free": (None, [vp]),
+        "mi_host_register": (i32, [vp, sz]),
+        "mi_host_unregister": (None, [vp]),
+        "mi_device_copy_rate": (i32, [i32, sz, i32, f64p]),
         "mi_engine_rebind": (i32, [vp, vp, i32]),
         "mi_filter_generation": (C.c_ulonglong, [vp]),
         "mi_engine_last_generation": (C.c_ulonglong, [vp]),
@@ -127,6 +131,10 @@ def _load():
         "mi_multi_in_frames_per_block": (sz, [vp]),
         "mi_multi_out_frames_per_block": (sz, [vp]),
         "mi_multi_device_of_stream": (i32, [vp, i32]),
+        "mi_multi_device_of_channel": (i32, [vp, i32]),
+        "mi_multi_partition_channels": (i32, [i32, i32, C.POINTER(i32)]),
+        "mi_multi_worker_cpus": (i32, [vp, i32, cp, sz]),
+        "mi_debug_multi_fail_next_eq_on_slot": (None, [vp, i32]),
         "mi_multi_partition": (i32, [i32, i32, C.POINTER(i32)]),
         "mi_bank_load": (i32, [i32, cp, C.POINTER(vp), cp, sz, cp, sz]),
         "mi_bank_release": (None, [vp]),
@@ -167,6 +175,7 @@ def _load():
         "mi_lds_swizzle": (i32, [i32]),
         "mi_fused_set_of_block": (i32, [i32, i32]),
         "mi_fused_block_a": (i32, [i32, i32]),
+        "mi_fused_plan_radices": (i32, [i32, C.POINTER(i32), sz]),
         "mi_tables_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -184,11 +193,13 @@ EXPORTED_SYMBOLS = [
     "mi_ups_set_eq", "mi_filter_load", "mi_filter_from_taps", "mi_filter_get_config", "mi_filter_set_eq",
     "mi_eq_response_device", "mi_filter_release", "mi_engine_create", "mi_engine_destroy", "mi_engine_reset",
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
-    "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_engine_rebind", "mi_filter_generation",
+    "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_host_register", "mi_host_unregister",
+    "mi_device_copy_rate", "mi_engine_rebind", "mi_filter_generation",
     "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_last_kernel_ms",
     "mi_engine_kernel_ms_stats", "mi_engine_enable_class_timing", "mi_engine_last_class_ms", "mi_opra_to_apo", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
     "mi_multi_process_host", "mi_multi_in_frames_per_block", "mi_multi_out_frames_per_block",
-    "mi_multi_device_of_stream", "mi_multi_partition", "mi_bank_load", "mi_bank_release", "mi_bank_size",
+    "mi_multi_device_of_stream", "mi_multi_partition", "mi_multi_device_of_channel", "mi_multi_partition_channels",
+    "mi_multi_worker_cpus", "mi_debug_multi_fail_next_eq_on_slot", "mi_bank_load", "mi_bank_release", "mi_bank_size",
     "mi_bank_entry", "mi_bank_select", "mi_rate_family", "mi_same_family", "mi_upsample_ratio", "mi_negotiate",
     "mi_parse_runtime_config", "mi_ring_create", "mi_ring_destroy", "mi_ring_write", "mi_ring_read",
     "mi_ring_available_to_read", "mi_ring_available_to_write", "mi_ring_clear", "mi_stream_loop_run",
@@ -197,6 +208,7 @@ EXPORTED_SYMBOLS = [
     "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
     "mi_eq_magnitude_host", "mi_tables_build", "mi_tables_geometry", "mi_tables_size", "mi_tables_copy",
     "mi_tables_free", "mi_tables_block_b", "mi_lds_swizzle", "mi_fused_set_of_block", "mi_fused_block_a",
+    "mi_fused_plan_radices",
 ]
 
 
@@ -422,7 +434,11 @@ class MultiEngine:
     per slot, no exchange between devices (mi_multi_*)."""
 
     def __init__(self, json_path, devices, streams: int, channels: int, in_fmt: int = PCM_S32, out_fmt: int = PCM_S32,
-                 flags: int = LOAD_DEFAULT):
+                 flags: int = LOAD_DEFAULT, split_channels: bool = False):
+        """split_channels: cut every stream's channels into len(devices) contiguous groups instead of dealing whole
+        streams (MI_MULTI_SPLIT_CHANNELS)."""
+        if split_channels:
+            flags |= MULTI_SPLIT_CHANNELS
         self.devices = list(devices)
         self.streams, self.channels, self.in_fmt, self.out_fmt = streams, channels, in_fmt, out_fmt
         h = C.c_void_p()
@@ -444,6 +460,15 @@ class MultiEngine:
 
     def device_of_stream(self, s: int) -> int:
         return int(lib.mi_multi_device_of_stream(self._h, s))
+
+    def device_of_channel(self, c: int) -> int:
+        return int(lib.mi_multi_device_of_channel(self._h, c))
+
+    def worker_cpus(self, slot: int) -> str:
+        out = C.create_string_buffer(1024)
+        if lib.mi_multi_worker_cpus(self._h, slot, out, len(out)) != MI_OK:
+            raise UpsamplerError("mi_multi_worker_cpus")
+        return out.value.decode()
 
     def set_eq(self, apo_text: str, fs_out: float) -> None:
         if lib.mi_multi_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
@@ -509,6 +534,32 @@ class FilterBank:
         if getattr(self, "_h", None):
             lib.mi_bank_release(self._h)
             self._h = None
+
+    __del__ = close
+
+
+def device_copy_rate(device: int = 0, nbytes: int = 1 << 30, iters: int = 5) -> float:
+    """GB/s (read + write) of a plain device-to-device copy kernel on this box (mi_device_copy_rate)."""
+    out = C.c_double()
+    if lib.mi_device_copy_rate(device, nbytes, iters, C.byref(out)) != MI_OK:
+        raise UpsamplerError(last_error())
+    return float(out.value)
+
+
+class RegisteredBuffer:
+    """A numpy array the caller owns, page-locked in place for DMA (mi_host_register) until close()."""
+
+    def __init__(self, array: np.ndarray):
+        self.array = array
+        self._p = array.ctypes.data
+        if lib.mi_host_register(C.c_void_p(self._p), array.nbytes) != MI_OK:
+            self._p = None
+            raise UpsamplerError(last_error())
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib.mi_host_unregister(C.c_void_p(self._p))
+            self._p = None
 
     __del__ = close
 
@@ -604,6 +655,13 @@ def opra_to_apo(record, modern_target: bool = False) -> str:
     return out.value.decode()
 
 
+def multi_partition_channels(channels: int, slots: int) -> list[int]:
+    out = (C.c_int * (slots + 1))()
+    if lib.mi_multi_partition_channels(channels, slots, out) != MI_OK:
+        raise UpsamplerError("mi_multi_partition_channels")
+    return list(out)
+
+
 def multi_partition(streams: int, slots: int) -> list[int]:
     out = (C.c_int * max(streams, 1))()
     if lib.mi_multi_partition(streams, slots, out) != MI_OK:
@@ -617,7 +675,7 @@ def stream_loop_run(params: dict, read, write, process=None, between=None, log=N
     fb = PCM_BYTES[params["format"]] * params["channels"]
     lp = _LoopParams(params["channels"], params["format"], params["period_frames"], params.get("block_in_frames", 0),
                      params.get("block_out_frames", 0), params.get("max_blocks_per_call", 1),
-                     int(params.get("drain_at_end", False)))
+                     int(params.get("drain_at_end", False)), int(params.get("pinned_rings", False)))
 
     def _read(_u, dst, frames):
         data = read(frames)
@@ -709,6 +767,14 @@ def eq_response_device(text: str, num_bins: int, full_fft: int, fs_out: float, d
     if lib.mi_eq_response_device(device, text.encode(), num_bins, full_fft, fs_out, _f64(out.view(np.float64))) != MI_OK:
         raise UpsamplerError(last_error())
     return out
+
+
+def fused_plan_radices(log2k: int) -> list[int]:
+    out = (C.c_int * 8)()
+    n = lib.mi_fused_plan_radices(log2k, out, 8)
+    if n < 0:
+        raise UpsamplerError("mi_fused_plan_radices")
+    return list(out[:n])
 
 
 def build_tables(json_path, flags: int = LOAD_DEFAULT, apo_text: str | None = None, fs_out: float = 0.0) -> dict:

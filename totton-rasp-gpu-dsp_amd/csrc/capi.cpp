@@ -420,6 +420,32 @@ int mi_engine_process_host(mi_engine *e, const void *h_in, size_t in_stream_stri
       MI_ERR_DEVICE);
 }
 
+int mi_host_register(void *p, size_t bytes) {
+  return Guard(
+      [&]() -> int {
+        std::string error;
+        if (!miups::HostRegister(p, bytes, &error)) {
+          return Fail(MI_ERR_DEVICE, error);
+        }
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
+void mi_host_unregister(void *p) { miups::HostUnregister(p); }
+
+int mi_device_copy_rate(int device, size_t bytes, int iters, double *gbps) {
+  return Guard(
+      [&]() -> int {
+        std::string error;
+        if (!miups::DeviceCopyRate(device, bytes, iters, gbps, &error)) {
+          return Fail(MI_ERR_DEVICE, error);
+        }
+        return MI_OK;
+      },
+      MI_ERR_DEVICE);
+}
+
 void *mi_host_alloc(size_t bytes) {
   return Guard(
       [&]() -> void * {
@@ -508,8 +534,9 @@ int mi_multi_create(const char *json_path, int flags, const int *devices, size_t
         if (!miups::ReadFilter(json_path, &config, &taps, &error)) {
           return Fail(MI_ERR_FILTER, error, err, errcap);
         }
-        auto m = miups::MultiEngine::Create(std::vector<int>(devices, devices + n_devices), config, taps, flags, streams,
-                                            channels, in_fmt, out_fmt, &error);
+        const int split = (flags & MI_MULTI_SPLIT_CHANNELS) ? miups::kSplitChannels : miups::kSplitStreams;
+        auto m = miups::MultiEngine::Create(std::vector<int>(devices, devices + n_devices), config, taps,
+                                            flags & ~MI_MULTI_SPLIT_CHANNELS, streams, channels, in_fmt, out_fmt, &error, split);
         if (!m) {
           return Fail(MI_ERR_DEVICE, error, err, errcap);
         }
@@ -565,6 +592,33 @@ size_t mi_multi_in_frames_per_block(const mi_multi *m) { return m ? static_cast<
 size_t mi_multi_out_frames_per_block(const mi_multi *m) { return m ? static_cast<size_t>(m->multi->geometry().B) : 0; }
 int mi_multi_device_of_stream(const mi_multi *m, int stream) {
   return (m && stream >= 0 && stream < m->multi->streams()) ? m->multi->deviceOfStream(stream) : -1;
+}
+
+int mi_multi_device_of_channel(const mi_multi *m, int channel) {
+  return (m && channel >= 0 && channel < m->multi->channels()) ? m->multi->deviceOfChannel(channel) : -1;
+}
+
+int mi_multi_partition_channels(int channels, int slots, int *first_channel_of_slot) {
+  if (channels < 0 || slots <= 0 || !first_channel_of_slot) {
+    return MI_ERR_ARG;
+  }
+  const std::vector<int> p = miups::PartitionChannels(channels, slots);
+  std::copy(p.begin(), p.end(), first_channel_of_slot);
+  return MI_OK;
+}
+
+int mi_multi_worker_cpus(const mi_multi *m, int slot, char *out, size_t cap) {
+  if (!m || slot < 0 || slot >= m->multi->slots() || !out || cap == 0) {
+    return MI_ERR_ARG;
+  }
+  CopyMessage(m->multi->workerAffinity(slot), out, cap);
+  return MI_OK;
+}
+
+void mi_debug_multi_fail_next_eq_on_slot(mi_multi *m, int slot) {
+  if (m) {
+    m->multi->FailNextEqOnSlotForTest(slot);
+  }
 }
 
 int mi_multi_partition(int streams, int slots, int *slot_of_stream) {

@@ -299,9 +299,21 @@ int mi_tables_block_b(const mi_tables *t, int *out, size_t cap) {
 
 int mi_lds_swizzle(int word_index) { return miups::lds_swz(word_index); }
 
-int mi_fused_set_of_block(int block, int log2k) { return miups::FusedSetOfBlock(block, log2k); }
+// layout facts of the product's (classic) pass plan
+int mi_fused_set_of_block(int block, int log2k) { return miups::FusedSetOfBlock(block, log2k, false); }
 
-int mi_fused_block_a(int tau, int log2k) { return miups::FusedBlockA(tau, log2k); }
+int mi_fused_block_a(int tau, int log2k) { return miups::FusedBlockA(tau, log2k, false); }
+
+int mi_fused_plan_radices(int log2k, int *out, size_t cap) {
+  const std::vector<int> r = miups::FusedRadices(log2k, false);
+  if (!out || cap < r.size()) {
+    return -1;
+  }
+  for (std::size_t i = 0; i < r.size(); ++i) {
+    out[i] = r[i];
+  }
+  return static_cast<int>(r.size());
+}
 
 void mi_tables_free(mi_tables *t) { delete t; }
 
@@ -408,7 +420,7 @@ size_t mi_ring_available_to_read(const mi_ring *r) { return r ? r->ring.Availabl
 size_t mi_ring_available_to_write(const mi_ring *r) { return r ? r->ring.AvailableToWrite() : 0; }
 void mi_ring_clear(mi_ring *r) {
   if (r) {
-    r->ring.Clear();
+    r->ring.DiscardAll();
   }
 }
 
@@ -427,6 +439,10 @@ int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn wri
   lp.blockOutFrames = p->block_out_frames;
   lp.maxBlocksPerCall = p->max_blocks_per_call;
   lp.drainAtEnd = p->drain_at_end != 0;
+  if (p->pinned_rings) {
+    lp.hostAlloc = mi_host_alloc;
+    lp.hostFree = mi_host_free;
+  }
   miups::LoopStats st;
   miups::ProcessFn proc;
   if (process) {
@@ -453,6 +469,7 @@ int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn wri
     stats->input_overflows = st.inputOverflows;
     stats->output_overflows = st.outputOverflows;
     stats->process_calls = st.processCalls;
+    stats->in_place_calls = st.inPlaceCalls;
   }
   return ok ? MI_OK : MI_ERR_DEVICE;
 }

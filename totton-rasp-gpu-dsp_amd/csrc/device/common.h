@@ -57,6 +57,18 @@ float xchg_xor(float v, unsigned mask);  // value of thread (threadIdx.x ^ mask)
 #define MI_RESTRICT __restrict__
 #endif
 
+#if defined(MIUPS_HOST_EMU)
+#define MI_SCHED_FENCE()
+#define MI_OPAQUE_VGPR(x)
+#else
+// nothing moves across it in the instruction scheduler (pins the order of load groups, store groups and butterflies)
+#define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Makes `x` look freshly defined: address arithmetic derived from it cannot be
+// hoisted out of the phase / channel loops (hipcc otherwise precomputes every
+// LDS / output offset of all passes and keeps >100 registers live -> spills).
+#define MI_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace miups {
 
 // complex float, 8 bytes, layout-compatible with float2 / std::complex<float>
@@ -169,6 +181,12 @@ struct alignas(16) f4 {
 MI_HD int lds_swz(int i) {
   return i ^ ((i >> 4) & 15) ^ ((i >> 5) & 8) ^ ((((i >> 8) ^ (i >> 9)) & 1) << 4);
 }
+
+// Pass plans of the fused kernel's in-LDS transform (kernel_fused.h FusedCfg): the classic plan (2^(log2k mod 4), 16, ..,
+// 16) is the product's; the radix-32 plan (K/512, 32, 16) exists for the wide form at K = 8192 and 16384 as a measured
+// experiment (profiles/r03_b_radix32.txt: one LDS round trip and one barrier fewer per transform, but +14 % VALU work and
+// ~70 spilled registers -> 0.72x). The host orders the spectrum tables by the plan's digit reversal.
+MI_HD constexpr bool fused_plan_r32_exists(int log2k, int w) { return w == 2 && log2k >= 13 && log2k <= 14; }
 
 // Tables read by the fused kernel, laid out per thread (the kernel's thread ->
 // frequency-bin assignment is fixed, so the host stores everything in the

@@ -42,19 +42,8 @@
 
 #include "common.h"
 #include "fft_radix.h"
-#include "kernels_generic.h"
 #include "pcm.h"
 
-#if defined(MIUPS_HOST_EMU)
-#define MI_SCHED_FENCE()
-#define MI_OPAQUE_VGPR(x)
-#else
-#define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Makes `x` look freshly defined: address arithmetic derived from it cannot be
-// hoisted out of the phase / channel loops (hipcc otherwise precomputes every
-// LDS / output offset of all passes and keeps >100 registers live -> spills).
-#define MI_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
-#endif
 
 // Diagnostic build only (-DMIUPS_STAMPS, library variant under lib_ablate/): lane 0 of
 // every wave of the first 32 workgroups records s_memtime at fixed points so that
@@ -290,16 +279,32 @@ MI_DEVICE BlockIo make_block_io(const Geometry &g, const IoDesc &io, int s, int 
 //                     (profiles/r02_a_ubench_valu_lds_rates.txt) -- the passes are VALU-issue bound. The two sets of a
 //                     mirror pair live in lanes l and l ^ 32 of one wave and trade eight values through
 //                     v_permlane32_swap (xchg32) on either side of the spectral product.
-template <int LOG2K, int W = 2>
+//
+// Pass plans (forward order; the inverse runs them backwards):
+//   classic: R0 = 2^(LOG2K mod 4), then radix 16 with strides .., 256, 16, 1      (K = 16384: 4 16 16 16)
+//   R32:     K/512 (16 or 32, stride 512), radix 32 (stride 16), radix 16 (stride 1) -- K = 8192 and 16384 only,
+//            wide form only: one pass, one LDS round trip and one barrier fewer per transform (16384: 32 32 16,
+//            8192: 16 32 16). A thread's radix-32 butterfly is its two radix-16 butterflies joined by one radix-2
+//            step in registers (fft_radix.h vdft32); the two passes next to the spectral stage are unchanged.
+//            EXPERIMENT (MIUPS_EXP_R32=1 on a -DMIUPS_WITH_R32 build): measured 0.72x of the classic plan
+//            (profiles/r03_b_radix32.txt) -- the radix-4 pass it removes is the cheap one (290 of ~2400 VALU
+//            instructions per phase), an unshared 31-power twiddle tree per butterfly replaces a shared 15-power one,
+//            and the 64-register butterfly beside the 68 registers of split spectrum spills ~70 registers.
+template <int LOG2K, int W = 2, bool R32_ = false>
 struct FusedCfg {
   static constexpr int K = 1 << LOG2K;
   static constexpr int J = K / 16;       // sixteen-word LDS blocks / radix-16 butterflies per pass
   static constexpr int T = K / (16 * W); // threads per workgroup
+  static constexpr bool R32 = R32_;
   static constexpr int R0 = 1 << (LOG2K % 4);
   static constexpr int LOG2R0 = LOG2K % 4;
   static constexpr int N16 = LOG2K / 4;  // radix-16 passes
+  // radix and stride of the pass next to HBM (first forward, last inverse); RF == 1: the classic plan's first pass is
+  // its stride-K/16 radix-16 pass
+  static constexpr int RF = R32 ? K / 512 : R0;
   // radix of the pass before the last one: its digit is the low digit of the block index
-  static constexpr int RL = (N16 >= 2) ? 16 : R0;
+  static constexpr int RL = R32 ? 32 : ((N16 >= 2) ? 16 : R0);
+  static_assert(!R32 || fused_plan_r32_exists(LOG2K, W), "the radix-32 plan covers the wide form at K = 8192, 16384");
   static constexpr int LDS_BYTES = K * 8;
   static constexpr int LDS_BYTES_SPLIT = K * 8 + 64 * 8;  // + FusedKernel::kXchWords
   static_assert(LOG2K >= 5 && LOG2K <= 14, "fused kernel covers K = 32 .. 16384");
@@ -317,14 +322,24 @@ struct FusedCfg {
 // generic form spent ~2 instructions per LDS access, a fifth of a pass): strides 1 and 16: one XOR with a constant
 // per access; stride 256: the swizzle term takes four values, so four bases per butterfly and every
 // access is base + immediate offset; stride >= 1024: one base + immediate offsets.
+//   radix 32, stride 16 (sub-transform length 512): word a*512 + t*16 + r; every swizzle term is an XOR with a
+//   constant of t or a bit of a -> byte(t) = p ^ C(t), one XOR per access;
+//   stride 512 (K = 512 R, one sub-transform): the swizzle only sees t through bit 9 -> two bases + immediate offsets.
 template <int R, int S>
 struct Bfly {
   int p;  // precomputed per butterfly
   int w;  // S == 16 only
-  int b4[S == 256 ? 4 : 1];  // S == 256: byte address of (p ^ swizzle term k)
+  int b4[S == 256 ? 4 : (S == 512 ? 2 : 1)];  // S == 256 / 512: byte address of (p ^ swizzle term k)
   MI_DEVICE explicit Bfly(int q) {
     if constexpr (S == 1) {
       p = lds_swz(16 * q);
+      w = 0;
+    } else if constexpr (S == 16 && R == 32) {
+      const int a = q >> 4, r = q & 15;
+      p = ((a * 512 + r) * 8) ^ ((a & 1) << 7);  // BYTE address of (a, r) with a's share of the swizzle
+      w = 0;
+    } else if constexpr (S == 512) {
+      p = lds_swz(q);  // q < 512
       w = 0;
     } else if constexpr (S == 16) {
       const int a = q >> 4, r = q & 15;
@@ -344,13 +359,22 @@ struct Bfly {
       for (int k = 0; k < 4; ++k) {
         b4[k] = (p ^ (((k & 1) << 3) | ((k >> 1) << 4))) * 8;
       }
+    } else if constexpr (S == 512) {
+      b4[0] = p * 8;
+      b4[1] = (p ^ 16) * 8;
     } else {
       b4[0] = 0;
     }
   }
+  // radix 32, stride 16: t*16 words, t's low four bits into the word's low four bits, t's bit 4 into bits 3 and 4
+  static MI_DEVICE constexpr int c32(int t) { return (t * 128) ^ ((t & 15) * 8) ^ ((t >> 4) * 192); }
   MI_DEVICE int at(int t) const {
     if constexpr (S == 1) {
       return p ^ t;
+    } else if constexpr (S == 16 && R == 32) {
+      return (p ^ c32(t)) >> 3;
+    } else if constexpr (S == 512) {
+      return (b4[t & 1] >> 3) + t * S;
     } else if constexpr (S == 16) {
       return p + ((17 * t) ^ w);
     } else if constexpr (S == 256) {
@@ -364,6 +388,10 @@ struct Bfly {
   MI_DEVICE int byte(int t) const {
     if constexpr (S == 1) {
       return (p * 8) ^ (t * 8);
+    } else if constexpr (S == 16 && R == 32) {
+      return p ^ c32(t);
+    } else if constexpr (S == 512) {
+      return b4[t & 1] + t * (S * 8);
     } else if constexpr (S == 16) {
       return ((p + w) * 8) ^ (136 * t);  // p holds bits >= 8 only and (17 t) ^ w < 256: the sum is an XOR
     } else if constexpr (S == 256) {
@@ -374,12 +402,13 @@ struct Bfly {
   }
 };
 
-template <int LOG2K, int W = 2>
+template <int LOG2K, int W = 2, bool R32 = false>
 struct FusedKernel {
-  using Cfg = FusedCfg<LOG2K, W>;
-  static constexpr int K = Cfg::K, J = Cfg::J, T = Cfg::T, R0 = Cfg::R0, N16 = Cfg::N16;
-  static constexpr int LOG2R0 = Cfg::LOG2R0;
-  static constexpr int S0 = K / R0;  // stride of the radix-R0 pass (= 16^N16)
+  using Cfg = FusedCfg<LOG2K, W, R32>;
+  static constexpr int K = Cfg::K, J = Cfg::J, T = Cfg::T, N16 = Cfg::N16;
+  // R0 / S0 below = radix and stride of the pass next to HBM under the kernel's plan (the classic plan's R0, or K/512)
+  static constexpr int R0 = Cfg::RF;
+  static constexpr int S0 = K / R0;  // stride of that pass (classic: 16^N16; R32: 512)
 
   static MI_DEVICE const cf &lds_ref(const cf *lds, int byte) {
     return *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(lds) + byte);
@@ -407,6 +436,46 @@ struct FusedKernel {
     for (int u = 0; u < R; ++u) {
       lds_ref(lds, b.byte(u)) = v[out_pos<R>(u)];
     }
+  }
+
+  // One butterfly's DFT and the store of its outputs, four at a time as the last butterfly stage produces them
+  // (fft_radix.h vdft16_emit): the LDS write path (~80 B/clk) is the slowest resource of a pass, and sixteen stores
+  // issued in one burst behind a thread's last butterfly drain while the whole workgroup waits at the barrier.
+  // kOut: output u is multiplied by w^u first (decimation in frequency); tw[u - 1] = w^u for u < 16, and for radix 32
+  // w16 = w^16 (the powers above sixteen are formed where they are used: sixteen live powers instead of thirty-one).
+  template <int DIR, int R, int S, bool kOut>
+  static MI_DEVICE void dft_put(cf *lds, const Bfly<R, S> &b, const cf *c, const v2 *tw, v2 w16 = v2{1.0f, 0.0f}) {
+    static_assert(R == 16 || R == 32, "emitting DFTs exist for radix 16 and 32");
+    v2 v[R];
+    MI_UNROLL
+    for (int i = 0; i < R; ++i) {
+      v[i] = V(c[i]);
+    }
+    auto emit = [&](int u, v2 y) {
+      if constexpr (kOut) {
+        if (u >= 1 && u < 16) {
+          y = vmul(y, tw[u - 1]);
+        } else if (u == 16) {
+          y = vmul(y, w16);
+        } else if (u > 16) {
+          y = vmul(y, vmul(w16, tw[u - 17]));
+        }
+      }
+      lds_ref(lds, b.byte(u)) = C(y);
+    };
+#if defined(MIUPS_EXP_NO_TRICKLE)  // experiment switch (profiles/r03_b_*): all stores behind the whole butterfly
+    vdftR<DIR, R>(v);
+    MI_UNROLL
+    for (int u = 0; u < R; ++u) {
+      emit(u, v[out_pos<R>(u)]);
+    }
+#else
+    if constexpr (R == 16) {
+      vdft16_emit<DIR>(v, emit);
+    } else {
+      vdft32_emit<DIR>(v, emit);
+    }
+#endif
   }
 
   template <int LOG2L>
@@ -538,11 +607,12 @@ struct FusedKernel {
 #endif
     return d;
   }
-  template <int R, bool kEvenOc, bool kNT = false>
+  // kUpper: only outputs u >= R/2 exist in v (pruned last pass: the lower half of the transform is discarded history)
+  template <int R, bool kEvenOc, bool kNT = false, bool kUpper = false>
   static MI_DEVICE void plane_write(const PlaneDst &d, int q, const cf *v) {
     if constexpr (kEvenOc) {
       MI_UNROLL
-      for (int u = 0; u < R; ++u) {
+      for (int u = kUpper ? R / 2 : 0; u < R; ++u) {
         const unsigned off = (static_cast<unsigned>(q) + static_cast<unsigned>(u) * (K / R)) * 8u - d.o2x8;
         const cf y = v[out_pos<R>(u)];
 #if defined(MIUPS_HOST_EMU)
@@ -596,9 +666,16 @@ struct FusedKernel {
         const int q = tid + i * T;
         cf v[R0];
         global_unpack<FMT, R0, MODE>(b, in[i], v);
-        dftR<-1, R0>(v);
-        apply_twiddles_out<-1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
-        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), v);
+        const cf wq = i == 0 ? w0 : cmul(w0, w32(i * (2 / W)));
+        if constexpr (R0 >= 16) {
+          v2 t[15];
+          make_twiddles<-1, 16>(V(wq), t);
+          dft_put<-1, R0, S0, true>(lds, Bfly<R0, S0>(q), v, t, vmul(t[7], t[7]));
+        } else {
+          dftR<-1, R0>(v);
+          apply_twiddles_out<-1, R0>(v, wq);
+          lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), v);
+        }
       }
     } else if constexpr (R0 > 1) {
       // every input load of the thread is issued before the first butterfly, so the
@@ -612,9 +689,16 @@ struct FusedKernel {
       MI_UNROLL
       for (int i = 0; i < NB; ++i) {
         const int q = tid + i * T;
-        dftR<-1, R0>(raw[i]);
-        apply_twiddles_out<-1, R0>(raw[i], i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
-        lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), raw[i]);
+        const cf wq = i == 0 ? w0 : cmul(w0, w32(i * (2 / W)));
+        if constexpr (R0 >= 16) {
+          v2 t[15];
+          make_twiddles<-1, 16>(V(wq), t);
+          dft_put<-1, R0, S0, true>(lds, Bfly<R0, S0>(q), raw[i], t, vmul(t[7], t[7]));
+        } else {
+          dftR<-1, R0>(raw[i]);
+          apply_twiddles_out<-1, R0>(raw[i], wq);
+          lds_put_dft<R0, S0>(lds, Bfly<R0, S0>(q), raw[i]);
+        }
       }
     } else if constexpr (W == 2 && MODE != 0) {
       Raw<MODE> ia[16], ib[16];
@@ -623,14 +707,16 @@ struct FusedKernel {
       MI_SCHED_FENCE();
       cf A[16], B[16];
       global_unpack<FMT, 16, MODE>(b, ia, A);
-      dft16<-1>(A);
-      apply_twiddles_out<-1, 16>(A, w0);
-      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      {
+        Tw16 ta;
+        make_twiddles16<-1>(w0, ta);
+        dft_put<-1, 16, K / 16, true>(lds, Bfly<16, K / 16>(tid), A, ta.t);
+      }
       MI_SCHED_FENCE();
       global_unpack<FMT, 16, MODE>(b, ib, B);
-      dft16<-1>(B);
-      apply_twiddles_out<-1, 16>(B, cmul(w0, w32(1)));
-      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
+      Tw16 tb;
+      make_twiddles16<-1>(cmul(w0, w32(1)), tb);
+      dft_put<-1, 16, K / 16, true>(lds, Bfly<16, K / 16>(tid + T), B, tb.t);
     } else if constexpr (W == 1) {
       cf A[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
@@ -641,13 +727,15 @@ struct FusedKernel {
       cf A[16], B[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
       global_read<FMT, 16, kHist, MODE, SP>(b, tid + T, B);
-      dft16<-1>(A);
-      apply_twiddles_out<-1, 16>(A, w0);
-      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      {
+        Tw16 ta;
+        make_twiddles16<-1>(w0, ta);
+        dft_put<-1, 16, K / 16, true>(lds, Bfly<16, K / 16>(tid), A, ta.t);
+      }
       MI_SCHED_FENCE();
-      dft16<-1>(B);
-      apply_twiddles_out<-1, 16>(B, cmul(w0, w32(1)));
-      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
+      Tw16 tb;
+      make_twiddles16<-1>(cmul(w0, w32(1)), tb);
+      dft_put<-1, 16, K / 16, true>(lds, Bfly<16, K / 16>(tid + T), B, tb.t);
     }
   }
   template <int FMT, int SP = 0>
@@ -698,22 +786,20 @@ struct FusedKernel {
     if constexpr (T % S == 0) {  // both butterflies use the same twiddle: one power tree (-9 % VALU in this pass)
       Tw16 tw16;
       make_twiddles16<-1>(wA, tw16);
-      dft16<-1>(A);
-      mul_twiddles16_out(A, tw16);
-      lds_put_dft<16, S>(lds, bA, A);
+      dft_put<-1, 16, S, true>(lds, bA, A, tw16.t);
       MI_SCHED_FENCE();
-      dft16<-1>(B);
-      mul_twiddles16_out(B, tw16);
-      lds_put_dft<16, S>(lds, bB, B);
+      dft_put<-1, 16, S, true>(lds, bB, B, tw16.t);
       return;
     }
-    dft16<-1>(A);
-    apply_twiddles_out<-1, 16>(A, wA);
-    lds_put_dft<16, S>(lds, bA, A);
+    {
+      Tw16 twA;
+      make_twiddles16<-1>(wA, twA);
+      dft_put<-1, 16, S, true>(lds, bA, A, twA.t);
+    }
     MI_SCHED_FENCE();
-    dft16<-1>(B);
-    apply_twiddles_out<-1, 16>(B, wB);
-    lds_put_dft<16, S>(lds, bB, B);
+    Tw16 twB;
+    make_twiddles16<-1>(wB, twB);
+    dft_put<-1, 16, S, true>(lds, bB, B, twB.t);
   }
   // last pass (stride 1, no twiddles): the thread's two sets stay in registers,
   // A[out_pos<16>(t)] = Z[a + t*J], B[out_pos<16>(t)] = Z[(J - a) + t*J]
@@ -729,11 +815,9 @@ struct FusedKernel {
   // first pass (stride 1): inputs in A/B (natural order), results into the
   // thread's own two LDS blocks
   static MI_DEVICE void inv_first(cf *lds, int blkA, int blkB, cf *A, cf *B) {
-    dft16<+1>(A);
-    lds_put_dft<16, 1>(lds, Bfly<16, 1>(blkA), A);
+    dft_put<+1, 16, 1, false>(lds, Bfly<16, 1>(blkA), A, nullptr);
     MI_SCHED_FENCE();
-    dft16<+1>(B);
-    lds_put_dft<16, 1>(lds, Bfly<16, 1>(blkB), B);
+    dft_put<+1, 16, 1, false>(lds, Bfly<16, 1>(blkB), B, nullptr);
   }
   template <int S>
   static MI_DEVICE void inv_mid(cf *lds, const cf *tw, int tid) {
@@ -758,25 +842,41 @@ struct FusedKernel {
       Tw16 tw16;
       make_twiddles16<+1>(wA, tw16);
       mul_twiddles16(A, tw16);
-      dft16<+1>(A);
-      lds_put_dft<16, S>(lds, bA, A);
+      dft_put<+1, 16, S, false>(lds, bA, A, nullptr);
       MI_SCHED_FENCE();
       mul_twiddles16(B, tw16);
-      dft16<+1>(B);
-      lds_put_dft<16, S>(lds, bB, B);
+      dft_put<+1, 16, S, false>(lds, bB, B, nullptr);
       return;
     }
     apply_twiddles<+1, 16>(A, wA);
-    dft16<+1>(A);
-    lds_put_dft<16, S>(lds, bA, A);
+    dft_put<+1, 16, S, false>(lds, bA, A, nullptr);
     MI_SCHED_FENCE();
     apply_twiddles<+1, 16>(B, wB);
-    dft16<+1>(B);
-    lds_put_dft<16, S>(lds, bB, B);
+    dft_put<+1, 16, S, false>(lds, bB, B, nullptr);
+  }
+  // R32 plan: the one middle pass, radix 32 with stride 16 (sub-transform length 512), one butterfly per thread
+  static MI_DEVICE void fwd_mid32(cf *lds, const cf *tw, int tid) {
+    const Bfly<32, 16> bf(tid);
+    cf X[32];
+    lds_get<32, 16>(lds, bf, X);
+    v2 t[15];
+    make_twiddles<-1, 16>(V(load_tw<9>(tw, tid & 15)), t);
+    dft_put<-1, 32, 16, true>(lds, bf, X, t, vmul(t[7], t[7]));
+  }
+  static MI_DEVICE void inv_mid32(cf *lds, const cf *tw, int tid) {
+    const Bfly<32, 16> bf(tid);
+    cf X[32];
+    lds_get<32, 16>(lds, bf, X);
+    apply_twiddles<+1, 32>(X, load_tw<9>(tw, tid & 15));
+    dft_put<+1, 32, 16, false>(lds, bf, X, nullptr);
   }
   // last pass: stride K/R, natural-order results -> staging plane
-  template <bool kEvenOc, bool kNT = false>
+  // kUpper (even history length only): the discarded history covers at least the lower half of the transform (Oc >= K,
+  // i.e. O/N >= 1/2: every shipped filter), so only the upper half of every butterfly's outputs is computed and stored
+  // (fft_radix.h vdftR_upper). The hardware range check still drops the discarded part of the upper half.
+  template <bool kEvenOc, bool kNT = false, bool kUpper = false>
   static MI_DEVICE void inv_last(float *plane_, int Oc, int nkeep, const cf *lds, const cf *tw, int tid) {
+    static_assert(!kUpper || (kEvenOc && W == 2 && !R32), "the pruned last pass exists for the wide classic form, even history");
     const PlaneDst plane = make_plane_dst(plane_, Oc, nkeep);
     const cf w0 = load_tw<LOG2K>(tw, tid);
     if constexpr (R0 > 1) {
@@ -786,12 +886,27 @@ struct FusedKernel {
         cf v[R0];
         lds_get<R0, S0>(lds, Bfly<R0, S0>(q), v);
         apply_twiddles<+1, R0>(v, i == 0 ? w0 : cmul(w0, w32(i * (2 / W))));
-        dftR<+1, R0>(v);
-        plane_write<R0, kEvenOc, kNT>(plane, q, v);
+        if constexpr (kUpper) {
+          dftR_upper<+1, R0>(v);
+        } else {
+          dftR<+1, R0>(v);
+        }
+        plane_write<R0, kEvenOc, kNT, kUpper>(plane, q, v);
         if ((i & 3) == 3) {
           MI_SCHED_FENCE();  // keep at most 4 butterflies' registers in flight
         }
       }
+    } else if constexpr (kUpper) {
+      cf A[16], B[16];
+      lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid + T), B);
+      apply_twiddles<+1, 16>(A, w0);
+      dftR_upper<+1, 16>(A);
+      plane_write<16, kEvenOc, kNT, true>(plane, tid, A);
+      MI_SCHED_FENCE();
+      apply_twiddles<+1, 16>(B, cmul(w0, w32(1)));
+      dftR_upper<+1, 16>(B);
+      plane_write<16, kEvenOc, kNT, true>(plane, tid + T, B);
     } else if constexpr (W == 1) {
       cf A[16];
       lds_get<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
@@ -1201,7 +1316,11 @@ struct FusedKernel {
         if (i < Bc) {
           MI_UNROLL
           for (int e = 0; e < R; ++e) {
+#if defined(MIUPS_EXP_EPI_NO_LOAD)  // timing experiment (profiles/r03_c_*): frames without reading the planes (WRONG results)
+            v[d][e] = static_cast<float>(i + e) * 1.0e-9f;
+#else
             v[d][e] = pl[e][i];
+#endif
           }
         }
       }
@@ -1210,6 +1329,13 @@ struct FusedKernel {
         const unsigned i = base + d * T;
         if (i < Bc) {
           char *dst = out_blk + static_cast<size_t>(i * static_cast<unsigned>(4 * R));
+#if defined(MIUPS_EXP_EPI_NO_STORE) && !defined(MIUPS_HOST_EMU)  // timing experiment (profiles/r03_c_*): planes read, no frame written
+          MI_UNROLL
+          for (int e = 0; e < R; ++e) {
+            asm volatile("" ::"v"(v[d][e]));
+          }
+          continue;
+#endif
           MI_UNROLL
           for (int e = 0; e < R; e += 4) {
             if constexpr (FMT == kF32) {
@@ -1223,7 +1349,13 @@ struct FusedKernel {
               w.b = static_cast<int32_t>(pcm_clamp(v[d][e + 1], 0.9999999f) * 2147483648.0f);
               w.c = static_cast<int32_t>(pcm_clamp(v[d][e + 2], 0.9999999f) * 2147483648.0f);
               w.d = static_cast<int32_t>(pcm_clamp(v[d][e + 3], 0.9999999f) * 2147483648.0f);
+#if defined(MIUPS_EXP_NT_FRAMES) && !defined(MIUPS_HOST_EMU)  // experiment switch (profiles/r03_c_*): streaming frame stores
+              typedef int i4v __attribute__((ext_vector_type(4)));
+              const i4v wv = {w.a, w.b, w.c, w.d};
+              __builtin_nontemporal_store(wv, reinterpret_cast<i4v *>(dst + 4 * e));
+#else
               *reinterpret_cast<I4 *>(dst + 4 * e) = w;
+#endif
             }
           }
         }
@@ -1471,8 +1603,14 @@ struct FusedKernel {
     MI_SYNC_PAIR();
     MI_STAMP(sb + 2);
     // radix-16 passes with strides 256 and 16 exist when K/R0 >= 4096 resp. >= 256
-    // (when R0 == 1 the first pass already was the stride-K/16 radix-16 pass)
-    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    // (when R0 == 1 the first pass already was the stride-K/16 radix-16 pass); R32 plan: one radix-32 pass
+    constexpr int kFirstMidStride = R32 ? 0 : ((R0 > 1) ? S0 / 16 : S0 / 256);
+    if constexpr (R32) {
+      fwd_mid32(lds, ft.tw, tid);
+      MI_STAMP(sb + 5);
+      MI_SYNC_PAIR();
+      MI_STAMP(sb + 6);
+    }
     if constexpr (kFirstMidStride >= 256) {
       fwd_mid<256>(lds, ft.tw, tid);
       MI_STAMP(sb + 3);
@@ -1553,7 +1691,7 @@ struct FusedKernel {
   static MI_DEVICE void channel_block_wide(const Geometry &g, const BlockIo &b, float *scr_c, const FusedTables &ft, cf *lds,
                                            int tid, int sb, bool evenOc, int rot) {
     (void)sb;
-    constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
+    constexpr int kFirstMidStride = R32 ? 0 : ((R0 > 1) ? S0 / 16 : S0 / 256);
     const int blkA = Cfg::block_a(tid);
     const int blkB = ft.blockB[tid];
     cf A[16], B[16];
@@ -1588,6 +1726,13 @@ struct FusedKernel {
       MI_STAMP(sp + 1);
       MI_SYNC_PAIR();
       MI_STAMP(sp + 2);
+      if constexpr (R32) {
+        MI_OPAQUE_VGPR(tl);
+        inv_mid32(lds, ft.tw, tl);
+        MI_STAMP(sp + 3);
+        MI_SYNC();
+        MI_STAMP(sp + 4);
+      }
       if constexpr (kFirstMidStride >= 16) {
         MI_OPAQUE_VGPR(tl);
         inv_mid<16>(lds, ft.tw, tl);
@@ -1608,8 +1753,18 @@ struct FusedKernel {
         inv_last<true, true>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
 #elif defined(MIUPS_EXP_NO_NT_PLANES)  // experiment switch (profiles/): cached plane stores for the interleave kernels too
         inv_last<true, false>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
-#else
+#elif defined(MIUPS_EXP_NO_PRUNE)  // experiment switch (profiles/r03_b_*): full last pass whatever the history length
         inv_last<true, EXT>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+#else
+        if constexpr (R32) {
+          inv_last<true, EXT>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+        } else if (R0 > 1 && b.Oc >= K) {  // workgroup-uniform: the lower half of every transform is discarded history
+          // (radix-16 last passes, K = 4096 / 256, keep the full form: the pruned one measured 1.3 % slower at config 3,
+          // profiles/r03_b_prune_trickle.txt)
+          inv_last<true, EXT, (R0 > 1)>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+        } else {
+          inv_last<true, EXT>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
+        }
 #endif
       } else {
         inv_last<false>(plane, b.Oc, g.Bc, lds, ft.tw, tl);
@@ -1627,6 +1782,7 @@ struct FusedKernel {
   // Oc % 4 == 0); the interleave kernels read that layout (IoDesc::split_planes).
   static MI_DEVICE void forward_half(const IoDesc &io, const BlockIo &b, const FusedTables &ft, cf *lds, int tid, cf *A,
                                      cf *B) {
+    static_assert(!R32, "the split form runs the classic pass plan (its 128 registers of spectrum leave no room for a radix-32 butterfly)");
     switch (io.in_fmt) {
       case kS32: fwd_first_fmt<kS32, 1>(b, lds, ft.tw, tid); break;
       case kF32: fwd_first_fmt<kF32, 1>(b, lds, ft.tw, tid); break;
@@ -1658,11 +1814,10 @@ struct FusedKernel {
       const int q = tid + i * T;
       const cf w = load_tw<LOG2L>(tw, q & (S - 1));
       const Bfly<16, S> bf(q);
-      cf V[16];
-      lds_get<16, S>(lds, bf, V);
-      apply_twiddles<+1, 16>(V, w);
-      dft16<+1>(V);
-      lds_put_dft<16, S>(lds, bf, V);
+      cf X[16];
+      lds_get<16, S>(lds, bf, X);
+      apply_twiddles<+1, 16>(X, w);
+      dft_put<+1, 16, S, false>(lds, bf, X, nullptr);
       MI_SCHED_FENCE();
     }
   }
@@ -1736,14 +1891,12 @@ struct FusedKernel {
       MI_SYNC();  // the self lanes' results are in thread 0's blocks
       // first inverse pass (stride 1), one block at a time, in place
       {
-        cf V[16];
-        lds_get<16, 1>(lds, bfA, V);
-        dft16<+1>(V);
-        lds_put_dft<16, 1>(lds, bfA, V);
+        cf X[16];
+        lds_get<16, 1>(lds, bfA, X);
+        dft_put<+1, 16, 1, false>(lds, bfA, X, nullptr);
         MI_SCHED_FENCE();
-        lds_get<16, 1>(lds, bfB, V);
-        dft16<+1>(V);
-        lds_put_dft<16, 1>(lds, bfB, V);
+        lds_get<16, 1>(lds, bfB, X);
+        dft_put<+1, 16, 1, false>(lds, bfB, X, nullptr);
       }
       MI_STAMP(sp + 1);
       MI_SYNC();
@@ -1763,7 +1916,15 @@ struct FusedKernel {
         MI_STAMP(sp + 6);
       }
       MI_OPAQUE_VGPR(tl);
+#if defined(MIUPS_EXP_NO_PRUNE)
       inv_last<true, true>(half, g.Oc >> 1, g.Bc >> 1, lds, ft.tw, tl);
+#else
+      if (R0 > 1 && (g.Oc >> 1) >= K) {  // the half transform's discarded history covers its lower half: pruned last pass
+        inv_last<true, true, (R0 > 1)>(half, g.Oc >> 1, g.Bc >> 1, lds, ft.tw, tl);
+      } else {
+        inv_last<true, true>(half, g.Oc >> 1, g.Bc >> 1, lds, ft.tw, tl);
+      }
+#endif
       MI_STAMP(sp + 7);
       MI_SYNC();
       MI_STAMP(sp + 8);
@@ -1823,11 +1984,12 @@ struct FusedKernel {
 // "1" hipcc parks 9-18 values of the K <= 8192 kernels in AGPRs instead of spilling them: 272 registers, ONE wave per
 // SIMD, and a lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5:
 // profiles/r02_a_ubench_valu_lds_rates.txt); the narrow form four waves per SIMD = at most 128 registers.
-template <int LOG2K, bool EXT, int W = 2>
+// R32: the experimental pass plan (FusedCfg); the host lays the tables out for the same plan (FilterTables::fusedR32).
+template <int LOG2K, bool EXT, int W = 2, bool R32 = false>
 MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : MIUPS_WIDE_WAVES)) void fused_kernel(
     Geometry g, IoDesc io, FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K, W>::template run<false, EXT>(g, io, ft, lds);
+  FusedKernel<LOG2K, W, R32>::template run<false, EXT>(g, io, ft, lds);
 }
 
 // Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see
@@ -1837,7 +1999,7 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 
                                                                                                             IoDesc io,
                                                                                                             FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
-  FusedKernel<LOG2K>::template run<true, true>(g, io, ft, lds);
+  FusedKernel<LOG2K, 2, false>::template run<true, true>(g, io, ft, lds);
 }
 
 }  // namespace miups

@@ -51,6 +51,16 @@ class DeviceFilter {
                                               double fsOut = 0.0);
   // Swap in tables with (or without, when text is empty) the EQ folded in. On failure the current tables stay.
   bool SetEq(const std::string &apoText, double fsOut, std::string *error);
+  // The same in two steps, for callers that change several filters together (MultiEngine: all slots or none): Stage
+  // builds and uploads the new table set without touching the live one; Publish swaps it in (cannot fail). A staged
+  // set that is dropped is freed.
+  struct Staged {
+    std::unique_ptr<TableSet> set;
+    Geometry geo{};
+    bool hasFused = false, fusedSplit = false, fusedNarrow = false, fusedR32 = false;
+  };
+  bool Stage(const std::string &apoText, double fsOut, Staged *out, std::string *error);
+  void Publish(Staged *staged);
   // A private copy with its own tables and EQ (used when one handle of several changes its EQ; empty text = no EQ).
   std::shared_ptr<DeviceFilter> Fork(const std::string &apoText, double fsOut, std::string *error) const;
 
@@ -60,6 +70,7 @@ class DeviceFilter {
   bool hasFused() const { return hasFused_; }
   bool fusedSplit() const { return fusedSplit_; }  // tables are laid out for fused_split_kernel
   bool fusedNarrow() const { return fusedNarrow_; }  // ... for the one-butterfly-per-thread form
+  bool fusedR32() const { return fusedR32_; }        // ... for the radix-32 pass plan (K = 8192, 16384)
   // current tables; the caller keeps the pointer for as long as enqueued work may read them
   std::shared_ptr<const TableSet> tables() const;
   unsigned long long generation() const;  // bumped by every successful SetEq
@@ -68,14 +79,14 @@ class DeviceFilter {
 
  private:
   DeviceFilter() = default;
-  bool Rebuild(const std::vector<std::complex<double>> *eqHalf, std::string *error);
+  bool StageTables(const std::vector<std::complex<double>> *eqHalf, Staged *out, std::string *error);
 
   int device_ = 0;
   FilterConfig config_{};
   std::vector<float> taps_;
   int flags_ = 0;
   Geometry geo_{};
-  bool hasFused_ = false, fusedSplit_ = false, fusedNarrow_ = false;
+  bool hasFused_ = false, fusedSplit_ = false, fusedNarrow_ = false, fusedR32_ = false;
   mutable std::mutex mu_;
   std::shared_ptr<const TableSet> cur_;
   std::shared_ptr<TablePool> pool_;
@@ -107,8 +118,12 @@ class Engine {
                      void *hipStream, std::string *error);
   // Host buffers: H2D / kernels / D2H of consecutive sub-batches overlap on three streams through double-buffered
   // device staging. Pinned host memory (mi_host_alloc) is copied by DMA directly; pageable memory works, slower.
+  // inFramePitch / outFramePitch (bytes, 0 = packed frames): the caller's frames are WIDER than this engine's -- the
+  // engine takes a contiguous channel group out of them (hIn / hOut already point at the group's first channel): the
+  // host copies become pitched 2-D copies (hipMemcpy2DAsync), nothing is de-interleaved on the host and no byte of
+  // another group's channels crosses this device's link (MultiEngine, channel split).
   bool ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std::size_t outStride, std::size_t blocks,
-                   std::string *error);
+                   std::string *error, std::size_t inFramePitch = 0, std::size_t outFramePitch = 0);
 
   const std::shared_ptr<DeviceFilter> &filter() const { return filter_; }
   bool fused() const { return fused_; }
@@ -186,6 +201,13 @@ class Engine {
 
 // Pinned host memory for ProcessHost callers (hipHostMalloc / hipHostFree).
 void *HostAlloc(std::size_t bytes, std::string *error);
+// Pin / unpin a caller's host buffer for DMA (hipHostRegister): what mi_host_alloc memory is from birth.
+bool HostRegister(void *p, std::size_t bytes, std::string *error);
+void HostUnregister(void *p);
+// Measured device-to-device copy rate of `device` (GB/s, bytes read + bytes written): 16 bytes per lane, grid-stride,
+// `bytes` per buffer, best of `iters` launches timed with hipEvents. The roofline's "what a plain copy reaches on this
+// box" beside the HBM spec figure.
+bool DeviceCopyRate(int device, std::size_t bytes, int iters, double *gbps, std::string *error);
 void HostFree(void *p);
 
 }  // namespace miups

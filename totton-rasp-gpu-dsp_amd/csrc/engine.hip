@@ -10,33 +10,20 @@
 #include <cstring>
 #include <sstream>
 
-#include "device/kernel_fused.h"
 #include "device/kernels_generic.h"
+#include "fused_launch.h"
+#include "hip_check.h"
 #include "host/eq.h"
+#if defined(MIUPS_SINGLE_TU)
+// experiment / diagnostic builds (scripts/build_variant.sh): everything in this one translation unit, so that
+// -DMIUPS_ONLY_LOG2K=n, -DMIUPS_STAMPS (one stamp buffer) and the other switches need a single compile
+#include "fused_launch_impl.h"
+#endif
 
 namespace miups {
 namespace {
 
 thread_local std::string g_lastError;
-
-bool HipOk(hipError_t e, const char *what, std::string *error) {
-  if (e == hipSuccess) {
-    return true;
-  }
-  std::ostringstream os;
-  os << what << ": " << hipGetErrorString(e);
-  if (error) {
-    *error = os.str();
-  }
-  return false;
-}
-
-#define MI_HIP(call)                       \
-  do {                                     \
-    if (!HipOk((call), #call, error)) {    \
-      return false;                        \
-    }                                      \
-  } while (0)
 
 bool UseDevice(int device, std::string *error) {
   int n = 0;
@@ -141,60 +128,6 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
   return src;
 }
 
-template <int LOG2K, bool EXT, int W>
-bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
-                        std::string *error) {
-  using Cfg = FusedCfg<LOG2K, W>;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  MI_HIP(hipGetDevice(&dev));
-  if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2K, EXT, W>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-    attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL((fused_kernel<LOG2K, EXT, W>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, ft);
-  return HipOk(hipGetLastError(), "fused_kernel launch", error);
-}
-
-// narrow = the tables are in the narrow layout (K >= 1024): one butterfly per thread
-template <int LOG2K>
-bool LaunchFused(const Geometry &g, const IoDesc &io, const FusedTables &ft, bool narrow, unsigned items, hipStream_t st,
-                 std::string *error) {
-  if constexpr (LOG2K >= 10) {
-#if !defined(MIUPS_NO_NARROW)
-    if (narrow) {
-      return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true, 1>(g, io, ft, items, st, error)
-                             : LaunchFusedVariant<LOG2K, false, 1>(g, io, ft, items, st, error);
-    }
-#endif
-  }
-  if (narrow) {
-    if (error) {
-      *error = "narrow tables without a narrow kernel";
-    }
-    return false;
-  }
-  return io.ext_epilogue ? LaunchFusedVariant<LOG2K, true, 2>(g, io, ft, items, st, error)
-                         : LaunchFusedVariant<LOG2K, false, 2>(g, io, ft, items, st, error);
-}
-
-template <int LOG2K>
-bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
-                      std::string *error) {
-  using Cfg = FusedCfg<LOG2K>;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  MI_HIP(hipGetDevice(&dev));
-  if (Cfg::LDS_BYTES_SPLIT > 64 * 1024 && dev < 64 && !attr_set[dev]) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_split_kernel<LOG2K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES_SPLIT));
-    attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io, ft);
-  return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
-}
-
 // interleave_tiled_kernel<FMT, TI, EPT>: TI in {64, 32, 16}, EPT = rows * TI / 1024 in 1..8
 template <int FMT, int TI>
 bool LaunchInterleaveTiledEpt(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ept,
@@ -237,34 +170,69 @@ bool LaunchInterleaveTiled(const Geometry &g, const IoDesc &io, const float *pla
   }
 }
 
-bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, bool narrow, unsigned items,
-                   hipStream_t st, std::string *error) {
+}  // namespace
+
+#if defined(MIUPS_SINGLE_TU)
+// the per-size entry points of fused_launch.h, defined here for the sizes this build holds
+#if !defined(MIUPS_ONLY_LOG2K)
+#define MI_FUSED_HERE(n) 1
+#else
+#define MI_FUSED_HERE(n) ((n) == MIUPS_ONLY_LOG2K)
+#endif
+#define MI_DEFINE_FUSED(n)                                                                                              \
+  bool LaunchFusedK##n(const Geometry &g, const IoDesc &io, const FusedTables &ft, bool narrow, bool r32, unsigned items, \
+                       hipStream_t st, std::string *error) {                                                          \
+    if constexpr (MI_FUSED_HERE(n)) {                                                                                 \
+      return LaunchFused<n>(g, io, ft, narrow, r32, items, st, error);                                                \
+    } else {                                                                                                          \
+      if (error) {                                                                                                    \
+        *error = "this experiment build holds no fused kernel for this transform length";                             \
+      }                                                                                                               \
+      return false;                                                                                                   \
+    }                                                                                                                 \
+  }
+MI_DEFINE_FUSED(5)
+MI_DEFINE_FUSED(6)
+MI_DEFINE_FUSED(7)
+MI_DEFINE_FUSED(8)
+MI_DEFINE_FUSED(9)
+MI_DEFINE_FUSED(10)
+MI_DEFINE_FUSED(11)
+MI_DEFINE_FUSED(12)
+MI_DEFINE_FUSED(13)
+MI_DEFINE_FUSED(14)
+#undef MI_DEFINE_FUSED
+bool LaunchFusedSplitK14(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
+                         std::string *error) {
+  if constexpr (MI_FUSED_HERE(15)) {
+    return LaunchFusedSplit<14>(g, io, ft, items, st, error);
+  } else {
+    if (error) {
+      *error = "this experiment build holds no split fused kernel";
+    }
+    return false;
+  }
+}
+#endif  // MIUPS_SINGLE_TU
+
+namespace {
+
+bool DispatchFused(const Geometry &g, const IoDesc &io, const FusedTables &f, bool split, bool narrow, bool r32,
+                   unsigned items, hipStream_t st, std::string *error) {
   if (split) {
     // block transform length K = 32768: two 16384-point transforms through the LDS
     // (the split layout is only built for that size outside the emulation tests)
-#if !defined(MIUPS_ONLY_LOG2K) || MIUPS_ONLY_LOG2K == 15
     if (g.log2k == 15) {
-      return LaunchFusedSplit<14>(g, io, f, items, st, error);
+      return LaunchFusedSplitK14(g, io, f, items, st, error);
     }
-#endif
     if (error) {
       *error = "split fused kernel does not cover this geometry";
     }
     return false;
   }
   switch (g.log2k) {
-// MIUPS_ONLY_LOG2K=n (scripts/build_variant.sh): experiment builds instantiate one transform length only (seconds, not minutes)
-#if !defined(MIUPS_ONLY_LOG2K)
 #define MI_FUSED_CASE(n) \
-  case n: return LaunchFused<n>(g, io, f, narrow, items, st, error);
-#else
-#define MI_FUSED_CASE(n)                                     \
-  case n:                                                    \
-    if constexpr (n == MIUPS_ONLY_LOG2K) {                   \
-      return LaunchFused<n>(g, io, f, narrow, items, st, error); \
-    }                                                        \
-    break;
-#endif
+  case n: return LaunchFusedK##n(g, io, f, narrow, r32, items, st, error);
     MI_FUSED_CASE(5)
     MI_FUSED_CASE(6)
     MI_FUSED_CASE(7)
@@ -398,6 +366,9 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
   if (std::getenv("MIUPS_EXP_NARROW")) {  // experiment switch (profiles/): one butterfly per thread, 4 waves per SIMD
     f->flags_ |= kLoadInternalNarrow;
   }
+  if (std::getenv("MIUPS_EXP_R32")) {  // experiment switch (profiles/r03_b_*): radix-32 pass plan at K = 8192 / 16384
+    f->flags_ |= kLoadInternalR32;
+  }
   f->pool_ = std::make_shared<TablePool>();
   if (!f->SetEq(apoText, fsOut, error)) {  // empty text: the plain filter
     return nullptr;
@@ -419,9 +390,9 @@ unsigned long long DeviceFilter::generation() const {
   return generation_;
 }
 
-// Build the new tables on the host, upload them into a set that nothing reads, then publish it. Whatever fails on
-// the way, the published set is untouched: engines keep running on the old spectrum and the error is returned.
-bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std::string *error) {
+// Build the new tables on the host and upload them into a set that nothing reads. Whatever fails on the way, the
+// published set is untouched: engines keep running on the old spectrum and the error is returned.
+bool DeviceFilter::StageTables(const std::vector<std::complex<double>> *eqHalf, Staged *out, std::string *error) {
   FilterTables t;
   if (!BuildTables(config_, taps_, eqHalf, flags_, &t, error)) {
     return false;
@@ -475,27 +446,49 @@ bool DeviceFilter::Rebuild(const std::vector<std::complex<double>> *eqHalf, std:
   }
   set->wb = t.Wb;
   set->wself = t.Wself;
-  std::lock_guard<std::mutex> lock(mu_);
-  if (!cur_) {
-    geo_ = t.geo;
-    hasFused_ = t.hasFused;
-    fusedSplit_ = t.fusedSplit;
-    fusedNarrow_ = t.fusedNarrow;
-  }
-  set->generation = ++generation_;
-  cur_ = std::shared_ptr<const TableSet>(set.release(), PoolReturn{pool_});
+  out->set = std::move(set);
+  out->geo = t.geo;
+  out->hasFused = t.hasFused;
+  out->fusedSplit = t.fusedSplit;
+  out->fusedNarrow = t.fusedNarrow;
+  out->fusedR32 = t.fusedR32;
   return true;
 }
 
-bool DeviceFilter::SetEq(const std::string &apoText, double fsOut, std::string *error) {
+void DeviceFilter::Publish(Staged *staged) {
+  if (!staged || !staged->set) {
+    return;
+  }
+  std::lock_guard<std::mutex> lock(mu_);
+  if (!cur_) {
+    geo_ = staged->geo;
+    hasFused_ = staged->hasFused;
+    fusedSplit_ = staged->fusedSplit;
+    fusedNarrow_ = staged->fusedNarrow;
+    fusedR32_ = staged->fusedR32;
+  }
+  staged->set->generation = ++generation_;
+  cur_ = std::shared_ptr<const TableSet>(staged->set.release(), PoolReturn{pool_});
+}
+
+bool DeviceFilter::Stage(const std::string &apoText, double fsOut, Staged *out, std::string *error) {
   if (apoText.empty()) {
-    return Rebuild(nullptr, error);
+    return StageTables(nullptr, out, error);
   }
   std::vector<std::complex<double>> half;
   if (!EqResponseDevice(device_, apoText, config_.fftSize / 2 + 1, config_.fftSize, fsOut, &half, error)) {
     return false;
   }
-  return Rebuild(&half, error);
+  return StageTables(&half, out, error);
+}
+
+bool DeviceFilter::SetEq(const std::string &apoText, double fsOut, std::string *error) {
+  Staged staged;
+  if (!Stage(apoText, fsOut, &staged, error)) {
+    return false;
+  }
+  Publish(&staged);
+  return true;
 }
 
 bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBins, std::size_t fullFft, double fsOut,
@@ -1095,8 +1088,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       ioF.item0 = static_cast<int>(p0 * groups_);
       ioF.scratch = planes;
       ClassMark(1, st, true);
-      if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), static_cast<unsigned>(np * groups_), st,
-                         error)) {
+      if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), filter_->fusedR32(),
+                         static_cast<unsigned>(np * groups_), st, error)) {
         return false;
       }
       ClassMark(1, st, false);
@@ -1242,7 +1235,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
 // j+1 is being copied in and j-1 copied out. (A block depends on earlier blocks only through the input history, which
 // ProcessDevice carries from one sub-batch to the next on the compute stream.) Synchronous for the caller.
 bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std::size_t outStride,
-                         std::size_t blocks, std::string *error) {
+                         std::size_t blocks, std::string *error, std::size_t inFramePitch, std::size_t outFramePitch) {
   if (!hIn || !hOut || blocks == 0) {
     if (error) {
       *error = "null buffer or zero blocks";
@@ -1255,7 +1248,20 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
   const Geometry &g = filter_->geometry();
   const std::size_t inBlock = static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
   const std::size_t outBlock = static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
-  if (streams_ > 1 && (inStride < blocks * inBlock || outStride < blocks * outBlock)) {
+  const std::size_t inFrame = static_cast<std::size_t>(channels_) * pcm_bytes(inFmt_);
+  const std::size_t outFrame = static_cast<std::size_t>(channels_) * pcm_bytes(outFmt_);
+  if ((inFramePitch && inFramePitch < inFrame) || (outFramePitch && outFramePitch < outFrame)) {
+    if (error) {
+      *error = "frame pitch smaller than this engine's frame";
+    }
+    return false;
+  }
+  const bool pitchedIn = inFramePitch > inFrame, pitchedOut = outFramePitch > outFrame;
+  // bytes one block takes in the CALLER's buffers
+  const std::size_t inBlockHost = pitchedIn ? static_cast<std::size_t>(g.n_in) * inFramePitch : inBlock;
+  const std::size_t outBlockHost = pitchedOut ? static_cast<std::size_t>(g.B) * outFramePitch : outBlock;
+  if (streams_ > 1 && (inStride < blocks * inBlockHost - (pitchedIn ? inFramePitch - inFrame : 0) ||
+                       outStride < blocks * outBlockHost - (pitchedOut ? outFramePitch - outFrame : 0))) {
     if (error) {
       *error = "stream stride smaller than one stream's data";
     }
@@ -1300,9 +1306,15 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
       MI_HIP(hipStreamWaitEvent(h2d, evRun, 0));  // the kernels of j-2 have read this input slot
     }
     for (int s = 0; s < streams_; ++s) {
-      MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow,
-                            static_cast<const char *>(hIn) + s * inStride + b0 * inBlock, nb * inBlock,
-                            hipMemcpyHostToDevice, h2d));
+      if (pitchedIn) {
+        MI_HIP(hipMemcpy2DAsync(static_cast<char *>(stageIn_[slot]) + s * inRow, inFrame,
+                                static_cast<const char *>(hIn) + s * inStride + b0 * inBlockHost, inFramePitch, inFrame,
+                                nb * static_cast<std::size_t>(g.n_in), hipMemcpyHostToDevice, h2d));
+      } else {
+        MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow,
+                              static_cast<const char *>(hIn) + s * inStride + b0 * inBlock, nb * inBlock,
+                              hipMemcpyHostToDevice, h2d));
+      }
     }
     MI_HIP(hipEventRecord(evIn, h2d));
     MI_HIP(hipStreamWaitEvent(own, evIn, 0));
@@ -1318,9 +1330,15 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     MI_HIP(hipEventRecord(evRun, own));
     MI_HIP(hipStreamWaitEvent(d2h, evRun, 0));
     for (int s = 0; s < streams_; ++s) {
-      MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlock,
-                            static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock,
-                            hipMemcpyDeviceToHost, d2h));
+      if (pitchedOut) {
+        MI_HIP(hipMemcpy2DAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlockHost, outFramePitch,
+                                static_cast<const char *>(stageOut_[slot]) + s * outRow, outFrame, outFrame,
+                                nb * static_cast<std::size_t>(g.B), hipMemcpyDeviceToHost, d2h));
+      } else {
+        MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlock,
+                              static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock,
+                              hipMemcpyDeviceToHost, d2h));
+      }
     }
     MI_HIP(hipEventRecord(evOut, d2h));
   }
@@ -1341,6 +1359,72 @@ void HostFree(void *p) {
   if (p) {
     (void)hipHostFree(p);
   }
+}
+
+bool HostRegister(void *p, std::size_t bytes, std::string *error) {
+  if (!p || bytes == 0) {
+    if (error) {
+      *error = "null buffer";
+    }
+    return false;
+  }
+  return HipOk(hipHostRegister(p, bytes, hipHostRegisterDefault), "hipHostRegister", error);
+}
+
+void HostUnregister(void *p) {
+  if (p) {
+    (void)hipHostUnregister(p);
+  }
+}
+
+namespace {
+__global__ void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, std::size_t n) {
+  const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+  for (std::size_t i = static_cast<std::size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    dst[i] = src[i];
+  }
+}
+}  // namespace
+
+bool DeviceCopyRate(int device, std::size_t bytes, int iters, double *gbps, std::string *error) {
+  if (!UseDevice(device, error)) {
+    return false;
+  }
+  if (bytes < 16 || iters < 1 || !gbps) {
+    if (error) {
+      *error = "bad copy-rate arguments";
+    }
+    return false;
+  }
+  const std::size_t n = bytes / 16;
+  void *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = HipOk(hipMalloc(&a, n * 16), "hipMalloc", error) && HipOk(hipMalloc(&b, n * 16), "hipMalloc", error) &&
+            HipOk(hipMemset(a, 1, n * 16), "hipMemset", error) && HipOk(hipEventCreate(&e0), "hipEventCreate", error) &&
+            HipOk(hipEventCreate(&e1), "hipEventCreate", error);
+  double best = 0.0;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  for (int i = 0; ok && i < iters + 1; ++i) {  // the first launch is a warm-up
+    ok = HipOk(hipEventRecord(e0, nullptr), "hipEventRecord", error);
+    hipLaunchKernelGGL(copy16_kernel, dim3(static_cast<unsigned>(cus) * 8), dim3(256), 0, nullptr,
+                       static_cast<const uint4 *>(a), static_cast<uint4 *>(b), n);
+    ok = ok && HipOk(hipEventRecord(e1, nullptr), "hipEventRecord", error) &&
+         HipOk(hipEventSynchronize(e1), "hipEventSynchronize", error);
+    float ms = 0.0f;
+    ok = ok && HipOk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime", error);
+    if (ok && i > 0 && ms > 0.0f) {
+      best = std::max(best, 2.0 * static_cast<double>(n) * 16.0 / (static_cast<double>(ms) * 1e-3) / 1e9);
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (ok) {
+    *gbps = best;
+  }
+  return ok;
 }
 
 bool Engine::EnableTiming(int slots, std::string *error) {

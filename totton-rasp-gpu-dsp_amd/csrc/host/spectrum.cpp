@@ -16,28 +16,17 @@ int Log2(std::size_t v) {
   return r;
 }
 
-// radices of the fused kernel's forward passes for K = 2^log2k
-std::vector<int> FusedRadices(int log2k) {
-  std::vector<int> r;
-  if (log2k % 4) {
-    r.push_back(1 << (log2k % 4));
-  }
-  for (int i = 0; i < log2k / 4; ++i) {
-    r.push_back(16);
-  }
-  return r;
-}
-
-void BuildFusedLayout(FilterTables *t) {
+void BuildFusedLayout(FilterTables *t, bool r32) {
   const Geometry &g = t->geo;
   t->hasFused = false;
   if (g.S != 1 || g.log2k < 5 || g.log2k > 14) {
     return;
   }
+  t->fusedR32 = r32;
   const int K = g.K, P = g.P, J = K / 16, T = K / 32;
   std::vector<int> blockOfSet(J);
   for (int b = 0; b < J; ++b) {
-    blockOfSet[FusedSetOfBlock(b, g.log2k)] = b;
+    blockOfSet[FusedSetOfBlock(b, g.log2k, r32)] = b;
   }
   t->WmT.assign(T, cf{1.0f, 0.0f});
   t->blockB.assign(T, 0);
@@ -51,7 +40,7 @@ void BuildFusedLayout(FilterTables *t) {
   };
   t->blockB[0] = blockOfSet[J / 2];
   for (int tau = 1; tau < T; ++tau) {
-    const int a = FusedSetOfBlock(FusedBlockA(tau, g.log2k), g.log2k);  // 0 < a < J/2
+    const int a = FusedSetOfBlock(FusedBlockA(tau, g.log2k, r32), g.log2k, r32);  // 0 < a < J/2
     t->WmT[tau] = t->Wm[a];
     t->blockB[tau] = blockOfSet[J - a];
     for (int p = 0; p < P; ++p) {
@@ -90,7 +79,7 @@ void BuildFusedNarrowLayout(FilterTables *t) {
   const int K = g.K, P = g.P, J = K / 16, T = K / 16;
   std::vector<int> blockOfSet(J);
   for (int b = 0; b < J; ++b) {
-    blockOfSet[FusedSetOfBlock(b, g.log2k)] = b;
+    blockOfSet[FusedSetOfBlock(b, g.log2k, false)] = b;
   }
   t->WmT.assign(T, cf{1.0f, 0.0f});
   t->blockB.assign(T, 0);
@@ -104,7 +93,7 @@ void BuildFusedNarrowLayout(FilterTables *t) {
   };
   for (int tid = 0; tid < T; ++tid) {
     const int tau = 32 * (tid >> 6) + (tid & 31), mirror = (tid >> 5) & 1;
-    const int a = tau == 0 ? 0 : FusedSetOfBlock(FusedBlockA(tau, g.log2k), g.log2k);  // 0 <= a < J/2
+    const int a = tau == 0 ? 0 : FusedSetOfBlock(FusedBlockA(tau, g.log2k, false), g.log2k, false);  // 0 <= a < J/2
     const int k0 = mirror ? (tau == 0 ? J / 2 : J - a) : a;
     t->blockB[tid] = blockOfSet[k0];
     t->WmT[tid] = t->Wm[k0];
@@ -134,7 +123,7 @@ bool BuildFusedSplitLayout(FilterTables *t) {
   const int K = g.K, Kh = K / 2, P = g.P, J = Kh / 16, T = Kh / 32;
   std::vector<int> blockOfSet(J);
   for (int b = 0; b < J; ++b) {
-    blockOfSet[FusedSetOfBlock(b, lh)] = b;
+    blockOfSet[FusedSetOfBlock(b, lh, false)] = b;  // the split form runs the classic plan
   }
   t->WmT.assign(T, cf{1.0f, 0.0f});
   t->blockB.assign(T, 0);
@@ -149,7 +138,7 @@ bool BuildFusedSplitLayout(FilterTables *t) {
   };
   t->blockB[0] = blockOfSet[J / 2];
   for (int tau = 1; tau < T; ++tau) {
-    const int a = FusedSetOfBlock(FusedBlockA(tau, lh), lh);  // 0 < a < J/2
+    const int a = FusedSetOfBlock(FusedBlockA(tau, lh, false), lh, false);  // 0 < a < J/2
     t->WmT[tau] = t->Wm[a];
     t->blockB[tau] = blockOfSet[J - a];
     for (int p = 0; p < P; ++p) {
@@ -177,10 +166,28 @@ bool BuildFusedSplitLayout(FilterTables *t) {
 
 }  // namespace
 
-int FusedSetOfBlock(int block, int log2k) {
+// radices of the fused kernel's forward passes for K = 2^log2k
+std::vector<int> FusedRadices(int log2k, bool r32) {
+  std::vector<int> r;
+  if (r32) {
+    r.push_back((1 << log2k) / 512);
+    r.push_back(32);
+    r.push_back(16);
+    return r;
+  }
+  if (log2k % 4) {
+    r.push_back(1 << (log2k % 4));
+  }
+  for (int i = 0; i < log2k / 4; ++i) {
+    r.push_back(16);
+  }
+  return r;
+}
+
+int FusedSetOfBlock(int block, int log2k, bool r32) {
   // block digits, most significant first, are the output digits u_0, u_1, ..
   // of the passes before the last; the set index has them least significant first
-  const std::vector<int> radices = FusedRadices(log2k);
+  const std::vector<int> radices = FusedRadices(log2k, r32);
   int stride = (1 << log2k);
   int set = 0, weight = 1;
   for (std::size_t i = 0; i + 1 < radices.size(); ++i) {
@@ -192,8 +199,8 @@ int FusedSetOfBlock(int block, int log2k) {
   return set;
 }
 
-int FusedBlockA(int tau, int log2k) {
-  const std::vector<int> radices = FusedRadices(log2k);
+int FusedBlockA(int tau, int log2k, bool r32) {
+  const std::vector<int> radices = FusedRadices(log2k, r32);
   const int rl = radices.size() >= 2 ? radices[radices.size() - 2] : 2;
   return (tau / (rl / 2)) * rl + (tau % (rl / 2));
 }
@@ -337,6 +344,7 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
   }
   out->fusedSplit = false;
   out->fusedNarrow = false;
+  out->fusedR32 = false;
   if (((flags & kLoadInternalForceSplit) || out->geo.log2k == 15) && BuildFusedSplitLayout(out)) {
     return true;
   }
@@ -344,7 +352,7 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
     BuildFusedNarrowLayout(out);  // one butterfly per thread, four waves per SIMD (experiment, see kernel_fused.h)
     return true;
   }
-  BuildFusedLayout(out);
+  BuildFusedLayout(out, fused_plan_r32_exists(out->geo.log2k, 2) && (flags & kLoadInternalR32) != 0);
   return true;
 }
 

@@ -36,6 +36,10 @@ struct FilterTables {
   // fusedNarrow: the layout is for fused_kernel<log2k, EXT, 1> (one butterfly per thread, T = K/16 lanes): WmT [T],
   // blockB [T] (each lane's own block), GT [P][8][T], G0 [P]. Experiment (kLoadInternalNarrow), 1024 <= K <= 16384.
   bool fusedNarrow = false;
+  // fusedR32: the plain wide layout follows the radix-32 pass plan (K = 8192, 16384: passes K/512, 32, 16) instead of the
+  // classic one (2^(log2k mod 4), 16, .., 16): another digit reversal, hence another block <-> set table. The kernel
+  // instantiation must match (fused_kernel<.., R32>).
+  bool fusedR32 = false;
   std::vector<cf> WmT;      // [T]
   std::vector<int> blockB;  // [T]
   std::vector<f4> GT;       // [P][16][T]
@@ -52,11 +56,16 @@ constexpr int kLoadInternalForceSplit = 0x100;
 // MIUPS_EXP_NARROW experiment switch; the product uses the wide form, which measured faster: profiles/r02_d_*)
 constexpr int kLoadInternalNarrow = 0x200;
 
-// Frequency layout of the fused kernel's in-place FFT (radices R0,16,..,16,
-// decimation in frequency): after the forward transform LDS block b holds the
-// bins {SetOfBlock(b) + t*K/16}. Exposed for the layout tests.
-int FusedSetOfBlock(int block, int log2k);
-int FusedBlockA(int tau, int log2k);  // first block of thread tau in the pairing passes
+// ... and: the radix-32 pass plan for the wide form at K = 8192 / 16384 (MIUPS_EXP_R32 experiment switch on a
+// -DMIUPS_WITH_R32 build, emulation tests; measured slower than the classic plan: profiles/r03_b_radix32.txt)
+constexpr int kLoadInternalR32 = 0x400;
+
+// Frequency layout of the fused kernel's in-place FFT (decimation in frequency, radices of the pass plan: classic
+// R0,16,..,16 or K/512,32,16): after the forward transform LDS block b holds the bins {SetOfBlock(b) + t*K/16}.
+// Exposed for the layout tests. r32: the radix-32 plan (see fused_plan_r32_exists in device/common.h).
+std::vector<int> FusedRadices(int log2k, bool r32);
+int FusedSetOfBlock(int block, int log2k, bool r32);
+int FusedBlockA(int tau, int log2k, bool r32);  // first block of thread tau in the pairing passes
 
 bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage);
 

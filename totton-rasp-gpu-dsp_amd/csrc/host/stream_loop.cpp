@@ -41,11 +41,28 @@ bool RunStreamLoop(const LoopParams &p, const ReadFn &read, const WriteFn &write
   std::vector<std::uint8_t> raw(p.periodFrames * frameBytes), outChunk(outPeriod * frameBytes);
   std::vector<float> scratch;
   PcmRing inRing, outRing;
-  std::vector<std::uint8_t> inBlocks, outBlocks;
+  std::vector<std::uint8_t> inBlocks, outBlocks;  // bounce buffers: only for a batch that wraps around a ring's end
+  struct RingMemory {  // ring storage from the caller's allocator (page-locked for the engine), released on every exit path
+    void *p = nullptr;
+    void (*release)(void *) = nullptr;
+    ~RingMemory() {
+      if (p && release) {
+        release(p);
+      }
+    }
+  } inMem, outMem;
   if (filtered) {
     // staging capacities: three times the larger of a block (batch) and a period (reference :476-481)
-    inRing.Init(std::max(p.blockInFrames * maxBlocks, p.periodFrames) * 3 * frameBytes);
-    outRing.Init(std::max(p.blockOutFrames * maxBlocks, outPeriod) * 3 * frameBytes);
+    const std::size_t inCap = std::max(p.blockInFrames * maxBlocks, p.periodFrames) * 3 * frameBytes;
+    const std::size_t outCap = std::max(p.blockOutFrames * maxBlocks, outPeriod) * 3 * frameBytes;
+    if (p.hostAlloc && p.hostFree) {
+      inMem.p = p.hostAlloc(inCap);
+      inMem.release = p.hostFree;
+      outMem.p = p.hostAlloc(outCap);
+      outMem.release = p.hostFree;
+    }
+    inRing.Init(inCap, inMem.p);
+    outRing.Init(outCap, outMem.p);
     inBlocks.resize(p.blockInFrames * maxBlocks * frameBytes);
     outBlocks.resize(p.blockOutFrames * maxBlocks * frameBytes);
   }
@@ -66,27 +83,41 @@ bool RunStreamLoop(const LoopParams &p, const ReadFn &read, const WriteFn &write
       if (k == 0) {
         break;
       }
-      const std::size_t want = k * p.blockInFrames * frameBytes;
-      if (tailBytes) {
-        std::fill(inBlocks.begin(), inBlocks.begin() + static_cast<std::ptrdiff_t>(want), 0);  // zero-padded (:301-304)
-        if (!inRing.Read(inBlocks.data(), tailBytes)) {
+      const std::size_t want = k * p.blockInFrames * frameBytes, produce = k * p.blockOutFrames * frameBytes;
+      // in place where the batch is one contiguous piece of the ring, through the bounce buffer where it wraps
+      PcmRing::Span rd[2], wr[2];
+      inRing.ReadableSpans(rd);
+      outRing.WritableSpans(wr);  // room >= k blocks was checked above
+      const bool inDirect = !tailBytes && rd[0].size >= want, outDirect = wr[0].size >= produce;
+      const std::uint8_t *src = rd[0].data;
+      if (!inDirect) {
+        src = inBlocks.data();
+        if (tailBytes) {
+          std::fill(inBlocks.begin(), inBlocks.begin() + static_cast<std::ptrdiff_t>(want), 0);  // zero-padded (:301-304)
+        }
+        if (!inRing.Read(inBlocks.data(), tailBytes ? tailBytes : want)) {
           return false;
         }
-      } else if (!inRing.Read(inBlocks.data(), want)) {
-        return false;
       }
+      std::uint8_t *dst = outDirect ? wr[0].data : outBlocks.data();
       if (between) {
         between();
       }
-      if (!process(inBlocks.data(), outBlocks.data(), k)) {
+      if (!process(src, dst, k)) {
         log("Filter output size mismatch");
         return false;
       }
+      if (inDirect) {
+        inRing.CommitRead(want);  // only now may the producer overwrite the blocks
+      }
       ++st.processCalls;
       st.blocksProcessed += k;
-      if (!outRing.Write(outBlocks.data(), k * p.blockOutFrames * frameBytes)) {
+      st.inPlaceCalls += (inDirect && outDirect) ? 1 : 0;
+      if (outDirect) {
+        outRing.CommitWrite(produce);
+      } else if (!outRing.Write(outBlocks.data(), produce)) {
         log("Output buffer overflow; dropping accumulated audio");
-        outRing.Clear();
+        outRing.DiscardAll();
         ++st.outputOverflows;
         break;
       }
@@ -101,7 +132,7 @@ bool RunStreamLoop(const LoopParams &p, const ReadFn &read, const WriteFn &write
         inputFrames += static_cast<std::size_t>(got);
         if (!inRing.Write(raw.data(), static_cast<std::size_t>(got) * frameBytes)) {
           log("Input buffer overflow; dropping accumulated audio");
-          inRing.Clear();
+          inRing.DiscardAll();
           ++st.inputOverflows;
         }
       } else if (got > 0 && !filtered && p.drainAtEnd) {
@@ -125,7 +156,7 @@ bool RunStreamLoop(const LoopParams &p, const ReadFn &read, const WriteFn &write
     }
     if (!inRing.Write(raw.data(), raw.size())) {
       log("Input buffer overflow; dropping accumulated audio");
-      inRing.Clear();
+      inRing.DiscardAll();
       ++st.inputOverflows;
     }
     if (!process_available(false)) {

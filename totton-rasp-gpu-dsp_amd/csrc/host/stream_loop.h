@@ -27,11 +27,17 @@ struct LoopParams {
   // additive (the reference stops at the first short read and leaves the staged tail unprocessed):
   // zero-pad the last partial block, process it, and write what remains -- truncated to inputFrames*ratio frames
   bool drainAtEnd = false;
+  // optional: where the two staging rings live. With the engine behind `process`, pass mi_host_alloc / mi_host_free:
+  // blocks are then handed to the engine IN PLACE in page-locked ring memory whenever a batch does not wrap
+  // (LoopStats::inPlaceCalls), so they cross the host once per side and are DMA-able without a staging copy.
+  void *(*hostAlloc)(std::size_t bytes) = nullptr;
+  void (*hostFree)(void *p) = nullptr;
 };
 
 struct LoopStats {
   std::size_t periodsRead = 0, blocksProcessed = 0, framesWritten = 0, silenceFramesWritten = 0;
   std::size_t inputOverflows = 0, outputOverflows = 0, processCalls = 0;
+  std::size_t inPlaceCalls = 0;  // process calls whose input AND output were contiguous pieces of the rings (no bounce copy)
 };
 
 // read: up to `frames` frames into dst, returns frames read (short = end of stream / stop)

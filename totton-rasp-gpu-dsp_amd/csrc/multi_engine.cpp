@@ -1,6 +1,13 @@
 #include "multi_engine.h"
 
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <fstream>
 
 namespace miups {
 
@@ -11,6 +18,76 @@ std::vector<int> PartitionStreams(int streams, int slots) {
   }
   return out;
 }
+
+std::vector<int> PartitionChannels(int channels, int slots) {
+  std::vector<int> out(static_cast<std::size_t>(std::max(slots, 0)) + 1, 0);
+  for (int i = 0; i <= slots; ++i) {
+    out[static_cast<std::size_t>(i)] = slots > 0 ? static_cast<int>(static_cast<long long>(i) * channels / slots) : 0;
+  }
+  return out;
+}
+
+std::string DeviceLocalCpuList(int device) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, static_cast<int>(sizeof(bus)), device) != hipSuccess) {
+    (void)hipGetLastError();
+    return std::string();
+  }
+  std::string id(bus);
+  std::transform(id.begin(), id.end(), id.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
+  std::ifstream f("/sys/bus/pci/devices/" + id + "/local_cpulist");
+  std::string list;
+  std::getline(f, list);
+  return list;
+}
+
+namespace {
+
+// "0-15,128-143" -> affinity of the calling thread, intersected with what the process may use. Returns the list
+// actually applied ("" when nothing was changed: unknown topology, or no CPU of the list is allowed here).
+std::string PinThisThread(const std::string &cpulist) {
+  if (cpulist.empty()) {
+    return std::string();
+  }
+  cpu_set_t allowed, want;
+  CPU_ZERO(&allowed);
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) {
+    return std::string();
+  }
+  std::size_t pos = 0;
+  int picked = 0;
+  while (pos < cpulist.size()) {
+    char *end = nullptr;
+    const long a = std::strtol(cpulist.c_str() + pos, &end, 10);
+    if (end == cpulist.c_str() + pos) {
+      break;
+    }
+    long b = a;
+    pos = static_cast<std::size_t>(end - cpulist.c_str());
+    if (pos < cpulist.size() && cpulist[pos] == '-') {
+      b = std::strtol(cpulist.c_str() + pos + 1, &end, 10);
+      pos = static_cast<std::size_t>(end - cpulist.c_str());
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+      if (c >= 0 && CPU_ISSET(static_cast<int>(c), &allowed)) {
+        CPU_SET(static_cast<int>(c), &want);
+        ++picked;
+      }
+    }
+    if (pos < cpulist.size() && cpulist[pos] == ',') {
+      ++pos;
+    } else {
+      break;
+    }
+  }
+  if (picked == 0 || pthread_setaffinity_np(pthread_self(), sizeof(want), &want) != 0) {
+    return std::string();
+  }
+  return cpulist;
+}
+
+}  // namespace
 
 MultiEngine::~MultiEngine() {
   {
@@ -27,10 +104,16 @@ MultiEngine::~MultiEngine() {
 
 std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices, const FilterConfig &config,
                                                  const std::vector<float> &taps, int flags, int streams, int channels,
-                                                 int inFmt, int outFmt, std::string *error) {
-  if (devices.empty() || streams <= 0) {
+                                                 int inFmt, int outFmt, std::string *error, int split) {
+  if (devices.empty() || streams <= 0 || channels <= 0) {
     if (error) {
-      *error = "need at least one device and one stream";
+      *error = "need at least one device, one stream and one channel";
+    }
+    return nullptr;
+  }
+  if (split != kSplitStreams && split != kSplitChannels) {
+    if (error) {
+      *error = "unknown partition";
     }
     return nullptr;
   }
@@ -46,14 +129,24 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
   }
   std::unique_ptr<MultiEngine> m(new MultiEngine());
   m->streams_ = streams;
+  m->channels_ = channels;
+  m->split_ = split;
+  m->inFmt_ = inFmt;
+  m->outFmt_ = outFmt;
   const int G = static_cast<int>(devices.size());
+  const std::vector<int> groups = PartitionChannels(channels, G);
   for (int i = 0; i < G; ++i) {
     std::unique_ptr<Slot> s(new Slot());
     s->index = i;
     s->device = devices[static_cast<std::size_t>(i)];
-    s->streams = (streams - i + G - 1) / G;  // streams i, i+G, i+2G, ...
-    if (s->streams < 0) {
-      s->streams = 0;
+    if (split == kSplitChannels) {
+      s->streams = streams;
+      s->c0 = groups[static_cast<std::size_t>(i)];
+      s->nch = groups[static_cast<std::size_t>(i) + 1] - s->c0;
+    } else {
+      s->streams = std::max(0, (streams - i + G - 1) / G);  // streams i, i+G, i+2G, ...
+      s->c0 = 0;
+      s->nch = channels;
     }
     // one filter per slot: slots on different devices cannot share tables, and slots on the same device are meant to
     // be independent (they model separate GPUs in the single-GPU tests)
@@ -61,8 +154,8 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
     if (!s->filter) {
       return nullptr;
     }
-    if (s->streams > 0) {
-      s->engine = Engine::Create(s->filter, s->streams, channels, inFmt, outFmt, error);
+    if (s->streams > 0 && s->nch > 0) {
+      s->engine = Engine::Create(s->filter, s->streams, s->nch, inFmt, outFmt, error);
       if (!s->engine) {
         return nullptr;
       }
@@ -75,7 +168,31 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
   return m;
 }
 
+bool MultiEngine::fused() const {
+  for (const auto &s : slots_) {
+    if (s->engine) {
+      return s->engine->fused();
+    }
+  }
+  return false;
+}
+
+int MultiEngine::deviceOfChannel(int c) const {
+  for (const auto &s : slots_) {
+    if (c >= s->c0 && c < s->c0 + s->nch) {
+      return s->device;
+    }
+  }
+  return -1;
+}
+
 void MultiEngine::WorkerMain(Slot *slot) {
+  // the worker feeds its device from host memory: keep it on the CPUs (and the memory controller) next to that device
+  const std::string pinned = PinThisThread(DeviceLocalCpuList(slot->device));
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    slot->cpus = pinned;
+  }
   for (;;) {
     Job job;
     {
@@ -89,12 +206,21 @@ void MultiEngine::WorkerMain(Slot *slot) {
     bool ok = true;
     std::string err;
     if (slot->engine) {
-      const int G = static_cast<int>(slots_.size());
-      // this slot's streams are s = index, index + G, ...: a strided view of the caller's buffers, no gather
-      ok = slot->engine->ProcessHost(static_cast<const char *>(job.hIn) + static_cast<std::size_t>(slot->index) * job.inStride,
-                                     job.inStride * static_cast<std::size_t>(G),
-                                     static_cast<char *>(job.hOut) + static_cast<std::size_t>(slot->index) * job.outStride,
-                                     job.outStride * static_cast<std::size_t>(G), job.blocks, &err);
+      const std::size_t G = slots_.size();
+      if (split_ == kSplitChannels) {
+        // this slot's channel group: a column of the caller's frames -- pitched copies, no gather on the host
+        const std::size_t ib = static_cast<std::size_t>(pcm_bytes(inFmt_)), ob = static_cast<std::size_t>(pcm_bytes(outFmt_));
+        ok = slot->engine->ProcessHost(static_cast<const char *>(job.hIn) + static_cast<std::size_t>(slot->c0) * ib,
+                                       job.inStride, static_cast<char *>(job.hOut) + static_cast<std::size_t>(slot->c0) * ob,
+                                       job.outStride, job.blocks, &err, static_cast<std::size_t>(channels_) * ib,
+                                       static_cast<std::size_t>(channels_) * ob);
+      } else {
+        // this slot's streams are s = index, index + G, ...: a strided view of the caller's buffers, no gather
+        ok = slot->engine->ProcessHost(
+            static_cast<const char *>(job.hIn) + static_cast<std::size_t>(slot->index) * job.inStride, job.inStride * G,
+            static_cast<char *>(job.hOut) + static_cast<std::size_t>(slot->index) * job.outStride, job.outStride * G,
+            job.blocks, &err);
+      }
     }
     {
       std::lock_guard<std::mutex> lock(mu_);
@@ -118,9 +244,8 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
   const Geometry &g = geometry();
   if (streams_ > 1) {
     // the strides are what separates one stream from the next: they must cover a stream's data
-    const Engine *e = slots_[0]->engine.get();
-    const std::size_t inRow = blocks * static_cast<std::size_t>(g.n_in) * e->channels() * pcm_bytes(e->inFmt());
-    const std::size_t outRow = blocks * static_cast<std::size_t>(g.B) * e->channels() * pcm_bytes(e->outFmt());
+    const std::size_t inRow = blocks * static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
+    const std::size_t outRow = blocks * static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
     if (inStride < inRow || outStride < outRow) {
       if (error) {
         *error = "stream stride smaller than one stream's data";
@@ -151,10 +276,25 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
 }
 
 bool MultiEngine::SetEq(const std::string &apoText, double fsOut, std::string *error) {
-  for (auto &s : slots_) {
-    if (!s->filter->SetEq(apoText, fsOut, error)) {
+  // phase 1: every slot's new tables, built and uploaded beside the live ones. phase 2: publish them all. A failure
+  // in phase 1 drops what was staged: no slot has changed. Called from the caller's thread between
+  // ProcessHost calls (ProcessHost is synchronous), so no worker is inside an engine call here.
+  std::vector<DeviceFilter::Staged> staged(slots_.size());
+  for (std::size_t i = 0; i < slots_.size(); ++i) {
+    if (failEqSlot_ == static_cast<int>(i)) {
+      failEqSlot_ = -1;
+      slots_[i]->filter->FailNextUploadForTest();
+    }
+    if (!slots_[i]->filter->Stage(apoText, fsOut, &staged[i], error)) {
+      if (error) {
+        *error = "slot " + std::to_string(i) + " (device " + std::to_string(slots_[i]->device) + "): " + *error +
+                 " -- no slot was changed";
+      }
       return false;
     }
+  }
+  for (std::size_t i = 0; i < slots_.size(); ++i) {
+    slots_[i]->filter->Publish(&staged[i]);
   }
   return true;
 }

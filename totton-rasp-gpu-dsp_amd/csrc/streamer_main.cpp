@@ -53,6 +53,7 @@ struct CliOptions {
   // additive
   int device = 0;
   std::vector<int> gpus;        // --gpus a,b,...: stream s runs on gpus[s mod n]
+  bool splitChannels = false;   // --split channels: contiguous channel groups of every stream per GPU instead
   unsigned streams = 1;         // file mode: the input file holds this many equal-length streams back to back
   unsigned blocksPerCall = 16;
   std::string eqPath;
@@ -86,6 +87,8 @@ void PrintUsage(const char *argv0) {
             << "  --buffer <frames>       ALSA buffer frames (default: period*4)\n"
             << "  --device <n>            HIP device index (default: 0)\n"
             << "  --gpus <a,b,...>        HIP devices to shard independent streams over (stream s -> gpus[s mod n])\n"
+            << "  --split <streams|channels>  with --gpus: whole streams per GPU (default), or the channels of every stream\n"
+            << "                          in contiguous groups, one group per GPU (one wide stream over several GPUs)\n"
             << "  --streams <n>           File mode: the input holds n equal-length streams back to back (default: 1)\n"
             << "  --blocks-per-call <n>   Filter blocks batched per GPU call (default: 16)\n"
             << "  --eq <path>             Equalizer-APO profile folded into the filter\n"
@@ -162,6 +165,13 @@ bool ParseArgs(int argc, char **argv, CliOptions *o) {
           ok = false;
         }
       }
+    } else if (arg == "--split") {
+      ok = value(&tmp);
+      if (ok && tmp != "streams" && tmp != "channels") {
+        std::cerr << "Invalid value for --split: " << tmp << "\n";
+        ok = false;
+      }
+      o->splitChannels = ok && tmp == "channels";
     } else if (arg == "--gpus") {
       ok = value(&tmp);
       std::stringstream ss(tmp);
@@ -246,7 +256,8 @@ bool PrepareFilter(const CliOptions &o, int fmt, Pipeline *p) {
   }
   mi_ups_config c;
   if (!o.gpus.empty()) {
-    if (mi_multi_create(path, MI_LOAD_DEFAULT, o.gpus.data(), o.gpus.size(), static_cast<int>(p->streams),
+    if (mi_multi_create(path, MI_LOAD_DEFAULT | (o.splitChannels ? MI_MULTI_SPLIT_CHANNELS : 0), o.gpus.data(), o.gpus.size(),
+                        static_cast<int>(p->streams),
                         static_cast<int>(o.channels), fmt, fmt, &p->multi, err, sizeof(err)) != MI_OK) {
       std::cerr << "Filter load failed: " << err << "\n";
       std::cerr << "Filter path: " << path << "\n";
@@ -775,6 +786,7 @@ int main(int argc, char **argv) {
   lp.block_out_frames = p.active() ? p.outFrames : 0;
   lp.max_blocks_per_call = std::max(1u, o.blocksPerCall);
   lp.drain_at_end = o.drain ? 1 : 0;
+  lp.pinned_rings = p.active() ? 1 : 0;  // the engine reads its blocks out of, and writes them into, page-locked ring memory
   mi_loop_stats st;
   std::cerr << (fileMode ? "File streaming started: input " : "ALSA streaming started: input ") << inputRate << " Hz, "
             << "output " << static_cast<unsigned long long>(inputRate) * p.factor << " Hz, "
