@@ -350,7 +350,8 @@ int mi_negotiate(int input_rate, int dac_valid, int dac_min_rate, int dac_max_ra
 }
 
 // ---- OPRA record -> APO text ---------------------------------------------------------------------------------
-int mi_opra_to_apo(const char *eq_json, int modern_target, char *out, size_t cap, size_t *needed, char *err, size_t errcap) {
+int mi_opra_to_apo(const char *eq_json, int modern_target, char *out, size_t cap, size_t *needed, char *err, size_t errcap)
+try {
   if (!eq_json || !out) {
     Put("null argument", err, errcap);
     return MI_ERR_ARG;
@@ -370,10 +371,16 @@ int mi_opra_to_apo(const char *eq_json, int modern_target, char *out, size_t cap
   std::memcpy(out, text.c_str(), text.size() + 1);
   Put("", err, errcap);
   return MI_OK;
+} catch (const std::exception &e) {  // no exception crosses the C boundary (std::bad_alloc on a huge record, ...)
+  Put(std::string("mi_opra_to_apo: ") + e.what(), err, errcap);
+  return MI_ERR_ARG;
+} catch (...) {
+  Put("mi_opra_to_apo: unknown exception", err, errcap);
+  return MI_ERR_ARG;
 }
 
 // ---- config.json -------------------------------------------------------------------------------------------
-int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char *err, size_t errcap) {
+int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char *err, size_t errcap) try {
   if (!json_text || !out) {
     Put("null argument", err, errcap);
     return MI_ERR_ARG;
@@ -400,6 +407,12 @@ int mi_parse_runtime_config(const char *json_text, mi_runtime_config *out, char 
   Put(c.outputDevice, out->output_device, sizeof(out->output_device));
   Put("", err, errcap);
   return MI_OK;
+} catch (const std::exception &e) {
+  Put(std::string("config parse error: ") + e.what(), err, errcap);
+  return MI_ERR_FILTER;
+} catch (...) {
+  Put("config parse error: unknown exception", err, errcap);
+  return MI_ERR_FILTER;
 }
 
 // ---- ring --------------------------------------------------------------------------------------------------
@@ -427,7 +440,7 @@ void mi_ring_clear(mi_ring *r) {
 // ---- streaming loop ----------------------------------------------------------------------------------------
 int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn write, mi_process_fn process,
                        mi_between_fn between, mi_log_fn log, void *user, const volatile int *running,
-                       mi_loop_stats *stats) {
+                       mi_loop_stats *stats) try {
   if (!p || !read || !write) {
     return MI_ERR_ARG;
   }
@@ -472,6 +485,8 @@ int mi_stream_loop_run(const mi_loop_params *p, mi_read_fn read, mi_write_fn wri
     stats->in_place_calls = st.inPlaceCalls;
   }
   return ok ? MI_OK : MI_ERR_DEVICE;
+} catch (...) {  // an exception out of a callback or an allocation: stop the loop, never unwind into C
+  return MI_ERR_DEVICE;
 }
 
 }  // extern "C"

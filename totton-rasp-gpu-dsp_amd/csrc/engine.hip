@@ -1378,10 +1378,27 @@ void HostUnregister(void *p) {
 }
 
 namespace {
+// four independent 16-byte loads per lane in flight, then four stores; a workgroup walks whole 16 KiB pieces
 __global__ void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, std::size_t n) {
-  const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
-  for (std::size_t i = static_cast<std::size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    dst[i] = src[i];
+  const std::size_t piece = static_cast<std::size_t>(blockDim.x) * 4;
+  const std::size_t stride = static_cast<std::size_t>(gridDim.x) * piece;
+  for (std::size_t base = static_cast<std::size_t>(blockIdx.x) * piece; base < n; base += stride) {
+    const std::size_t i = base + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const std::size_t j = i + static_cast<std::size_t>(k) * blockDim.x;
+      if (j < n) {
+        v[k] = src[j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const std::size_t j = i + static_cast<std::size_t>(k) * blockDim.x;
+      if (j < n) {
+        dst[j] = v[k];
+      }
+    }
   }
 }
 }  // namespace
@@ -1407,7 +1424,11 @@ bool DeviceCopyRate(int device, std::size_t bytes, int iters, double *gbps, std:
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   for (int i = 0; ok && i < iters + 1; ++i) {  // the first launch is a warm-up
     ok = HipOk(hipEventRecord(e0, nullptr), "hipEventRecord", error);
-    hipLaunchKernelGGL(copy16_kernel, dim3(static_cast<unsigned>(cus) * 8), dim3(256), 0, nullptr,
+    int perCu = 8;
+    if (const char *v = std::getenv("MIUPS_EXP_COPY_BLOCKS_PER_CU")) {  // experiment switch (profiles/r03_f_*)
+      perCu = std::max(1, std::atoi(v));
+    }
+    hipLaunchKernelGGL(copy16_kernel, dim3(static_cast<unsigned>(cus) * perCu), dim3(256), 0, nullptr,
                        static_cast<const uint4 *>(a), static_cast<uint4 *>(b), n);
     ok = ok && HipOk(hipEventRecord(e1, nullptr), "hipEventRecord", error) &&
          HipOk(hipEventSynchronize(e1), "hipEventSynchronize", error);

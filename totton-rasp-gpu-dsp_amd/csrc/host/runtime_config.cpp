@@ -12,7 +12,14 @@ namespace miups {
 namespace {
 
 // A small recursive-descent JSON reader: objects, arrays, strings, numbers, true/false/null. Values are flattened to
-// "section.key" -> text (strings unescaped, null -> empty marker) which is all the config needs.
+// "section<SEP>key" -> text (strings unescaped, null -> empty marker) which is all the config needs. SEP is a control
+// character, so a top-level key that merely CONTAINS a dot cannot pose as the nested one; the nesting depth is bounded
+// (the file is re-read on SIGHUP while audio is streaming: a hostile or damaged file must produce an error message,
+// not a stack overflow).
+constexpr char kSep = '\x1f';
+constexpr int kMaxDepth = 64;
+std::string Key(const char *section, const char *key) { return std::string(section) + kSep + key; }
+
 struct Reader {
   const std::string &s;
   std::size_t i = 0;
@@ -79,10 +86,13 @@ struct Reader {
     ++i;
     return true;
   }
-  bool Value(const std::string &path) {
+  bool Value(const std::string &path, int depth = 0) {
     Ws();
     if (i >= s.size()) {
       return Fail("unexpected end");
+    }
+    if (depth > kMaxDepth) {
+      return Fail("nesting deeper than " + std::to_string(kMaxDepth) + " levels");
     }
     const char c = s[i];
     if (c == '{') {
@@ -103,7 +113,7 @@ struct Reader {
           return Fail("expected ':'");
         }
         ++i;
-        if (!Value(path.empty() ? key : path + "." + key)) {
+        if (!Value(path.empty() ? key : path + kSep + key, depth + 1)) {
           return false;
         }
         Ws();
@@ -126,7 +136,7 @@ struct Reader {
         return true;
       }
       for (std::size_t n = 0;; ++n) {
-        if (!Value(path + "[" + std::to_string(n) + "]")) {
+        if (!Value(path + "[" + std::to_string(n) + "]", depth + 1)) {
           return false;
         }
         Ws();
@@ -217,16 +227,16 @@ bool ParseRuntimeConfig(const std::string &jsonText, RuntimeConfig *out, std::st
   c.eqEnabled = ToString(kv, "eqEnabled") == "true";
   c.eqProfile = ToString(kv, "eqProfile");
   c.eqProfilePath = ToString(kv, "eqProfilePath");
-  c.ratio = ToUnsigned(kv, "filter.ratio");
-  c.phaseType = ToString(kv, "filter.phaseType");
-  c.filterDirectory = ToString(kv, "filter.directory");
-  c.sampleRate = ToUnsigned(kv, "alsa.sampleRate");
-  c.channels = ToUnsigned(kv, "alsa.channels");
-  c.periodFrames = ToUnsigned(kv, "alsa.periodFrames");
-  c.bufferFrames = ToUnsigned(kv, "alsa.bufferFrames");
-  c.format = ToString(kv, "alsa.format");
-  c.inputDevice = ToString(kv, "alsa.inputDevice");
-  c.outputDevice = ToString(kv, "alsa.outputDevice");
+  c.ratio = ToUnsigned(kv, Key("filter", "ratio"));
+  c.phaseType = ToString(kv, Key("filter", "phaseType"));
+  c.filterDirectory = ToString(kv, Key("filter", "directory"));
+  c.sampleRate = ToUnsigned(kv, Key("alsa", "sampleRate"));
+  c.channels = ToUnsigned(kv, Key("alsa", "channels"));
+  c.periodFrames = ToUnsigned(kv, Key("alsa", "periodFrames"));
+  c.bufferFrames = ToUnsigned(kv, Key("alsa", "bufferFrames"));
+  c.format = ToString(kv, Key("alsa", "format"));
+  c.inputDevice = ToString(kv, Key("alsa", "inputDevice"));
+  c.outputDevice = ToString(kv, Key("alsa", "outputDevice"));
   *out = c;
   return true;
 }
