@@ -206,6 +206,14 @@ int mi_engine_last_class_ms(mi_engine *e, double *out4);
  * fails no slot changes.
  */
 #define MI_MULTI_SPLIT_CHANNELS 0x10000
+/*   MI_MULTI_SPLIT_TIME        the BLOCKS of every stream are cut into n_devices contiguous ranges, range i on slot i, all
+ *                              channels. Copies stay contiguous (full link rate per device: pitched DMA of narrow channel
+ *                              groups measured 3-11 GB/s against 54, profiles/r03_h_multi_split.txt). A block depends on
+ *                              earlier ones only through the input history, so each slot is handed the (taps-1)/L input
+ *                              frames in front of its range; the object keeps the tail of the previous call for the ranges
+ *                              at the start of the next one. Output is bit-identical to one engine. For calls of many
+ *                              blocks (file / batch processing); a one-block call runs on slot 0 alone. */
+#define MI_MULTI_SPLIT_TIME 0x20000
 typedef struct mi_multi mi_multi;
 int mi_multi_create(const char *json_path, int flags, const int *devices, size_t n_devices, int streams, int channels,
                     int in_fmt, int out_fmt, mi_multi **out, char *err, size_t errcap);

@@ -354,6 +354,12 @@ int main(int argc, char **argv) {
       }
       ioF.ext_epilogue = ext ? 1 : 0;
       ioF.split_planes = t.fusedSplit ? 1 : 0;
+      std::vector<f4> park;
+      ioF.park = nullptr;
+      if (t.fusedSplit && std::getenv("EMU_PARK")) {  // same rule as the engine (MIUPS_EXP_PARK: experiment, off by default)
+        park.assign(static_cast<size_t>(chunk) * groups * split_park_words(g.K / 64), f4{0.0f, 0.0f, 0.0f, 0.0f});
+        ioF.park = park.data();
+      }
       const bool quad = ioF.out_vec_ok && (outFmt == kF32 || outFmt == kS32) && (g.P * channels) % 4 == 0 && g.Bc % 4 == 0;
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);

@@ -332,6 +332,15 @@ def test_emulated_interleave_kernels_for_wide_frames(emu, O, make_filter, tmp_pa
         assert np.abs(y[:, c] - truth).max() <= 1e-5 * np.abs(truth).max() + lsb
 
 
+def test_emulated_split_form_with_parked_second_half(emu, O, make_filter, tmp_path, monkeypatch):
+    """The split form's experiment switch MIUPS_EXP_PARK (here EMU_PARK): a phase's second half transform takes its
+    first-pass inputs from a global-memory parking area instead of recomputing the spectral stage (measured slower on the
+    GPU, profiles/r03_g_split_park.txt; kept behind the switch, and kept correct)."""
+    monkeypatch.setenv("EMU_PARK", "1")
+    test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, 16384, 10241, 2, 1, 2, "s32", "s32")
+    test_emulated_split_form(emu, O, make_filter, tmp_path, monkeypatch, 4096, 1025, 1, 1, 1, "f32", "f32")
+
+
 @pytest.mark.parametrize("fft,taps,L,channels,in_fmt", [(8192, 2049, 2, 2, "s32"), (16384, 4097, 2, 3, "s16")])
 def test_emulated_split_form_from_interleaved_input(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, channels, in_fmt):
     """The split form's other input path (EMU_NO_SPLIT_PLANAR = the engine's MIUPS_EXP_NO_SPLIT_PLANAR, and what the

@@ -498,3 +498,37 @@ def test_full_size_properties(ups, gpu):
     c = np.full((blocks * nin, 2), 0.125, np.float32)
     y = eng.process_host(c, blocks).view(np.float32).reshape(blocks * B, 2)
     assert abs(y[-1000:, 0].mean() - 0.125 * h.astype(np.float64).sum() / L * 1.0) <= 1e-5
+
+
+# ---- "2m" (640 001-tap) filters: the ones the selector prefers when they are present -------------------------------------
+@pytest.mark.parametrize("ratio,phase,path_name", [
+    (16, "min", "fused"),     # N = 2^20, K = 32768: the split fused kernel
+    (8, "linear", "staged"),  # K = 65536: past the fused kernels, the staged (any-size) path
+])
+def test_640k_tap_filters_select_and_match_truth(ups, O, gpu, tmp_path, ratio, phase, path_name):
+    """alsa_filter_selector.cpp:74-96: "2m" files (640 000 specified taps) outrank the 80 000-tap ones. Designed here with
+    the repo's generator (filter_design.py, the reference recipe), selected through ResolveFilterPath next to a shorter
+    filter of the same key, loaded, and two blocks of two channels checked against fp64 truth."""
+    sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
+    import filter_design as fd
+
+    h = fd.design(640_000, ratio, "48k", phase)
+    assert h.size == 640_001
+    name = fd.base_name("48k", ratio, 640_000, phase)
+    assert name.endswith(f"_2m_{'min' if phase == 'min' else 'linear'}_phase")
+    big = fd.export(h, tmp_path, name, ratio)
+    fd.export(fd.design(8_000, ratio, "48k", phase), tmp_path, fd.base_name("48k", ratio, 8_000, phase), ratio)
+    chosen, msg = ups.resolve_filter_path("", str(tmp_path), phase, ratio, 48000)
+    assert chosen == str(big), (chosen, msg)
+    _, taps, fft, block, L = O.read_filter(big)
+    assert (taps, fft, L) == (640_001, 1 << 20, ratio) and block == fft - 640_000
+    filt = ups.Filter(big, device=gpu)
+    eng = ups.Engine(filt, 1, 2, ups.PCM_F32, ups.PCM_F32)
+    assert eng.path == path_name
+    blocks = 2
+    x = real_input(640 + ratio, blocks * eng.in_frames * 2).reshape(-1, 2)
+    y = eng.process_host(x, blocks).view(np.float32).reshape(blocks * block, 2)
+    h32 = np.fromfile(str(big).replace(".json", ".bin"), "<f4")
+    for c in range(2):
+        truth = O.truth_stream(x[:, c], h32, L, blocks, block).reshape(-1)
+        assert rel_err(y[:, c], truth) <= TOL_TRUTH

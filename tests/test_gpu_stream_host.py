@@ -94,6 +94,29 @@ def test_channel_split_is_bit_identical_to_one_engine(ups, gpu, fname, channels,
         assert isinstance(multi.worker_cpus(slot), str)   # "" where the platform gives no local_cpulist
 
 
+@pytest.mark.parametrize("devices,streams,channels,calls", [
+    ([0, 0], 1, 2, (5, 1, 4)),        # ranges that start less than one history into the call: context = old tail + new frames
+    ([0, 0, 0, 0], 2, 8, (9, 3, 6)),  # more slots than blocks in the second call: some slots idle; two streams, wide frames
+    ([0, 0, 0], 1, 32, (7,)),         # BASELINE configs[4] shape handled by block ranges
+])
+def test_time_split_is_bit_identical_to_one_engine(ups, gpu, devices, streams, channels, calls):
+    """MI_MULTI_SPLIT_TIME: contiguous block ranges of every stream per slot, all channels, contiguous copies. A block
+    depends on earlier blocks only through the input history (reference: overlap_ holds INPUT samples,
+    vulkan_streaming_upsampler.cpp:571-572), so a slot that is handed the hist_frames input frames in front of its range
+    produces exactly the bytes one engine produces there -- across calls of different lengths and after a reset."""
+    fname = "filter_48k_8x_160000_linear_phase" if channels == 32 else "filter_44k_4x_80000_min_phase"
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    filt = ups.Filter(path, device=gpu)
+    one = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
+    multi = ups.MultiEngine(path, devices, streams, channels, split_time=True)
+    for round_ in range(2):
+        for k, blocks in enumerate(calls):
+            x = synth(streams, blocks * one.in_frames, channels, seed=100 * round_ + k)
+            np.testing.assert_array_equal(multi.process_host(x, blocks), one.process_host(x, blocks))
+        multi.reset()
+        one.reset()
+
+
 def test_multi_engine_eq_change_is_all_or_nothing(ups, gpu):
     """mi_multi_set_eq builds every slot's tables first and publishes them together: a failure on slot 1 must leave slot 0
     on the OLD spectrum too (round-2 advisor finding: slots before the failing one had already switched)."""

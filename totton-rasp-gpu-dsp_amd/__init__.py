@@ -30,7 +30,7 @@ PCM_F32, PCM_S16, PCM_S24_3LE, PCM_S32 = 0, 1, 2, 3
 PCM_NAMES = {"f32": PCM_F32, "s16": PCM_S16, "s24": PCM_S24_3LE, "s32": PCM_S32}
 PCM_BYTES = {PCM_F32: 4, PCM_S16: 2, PCM_S24_3LE: 3, PCM_S32: 4}
 LOAD_DEFAULT, LOAD_REF_COMPAT_SPECTRUM = 0, 1
-MULTI_SPLIT_CHANNELS = 0x10000
+MULTI_SPLIT_CHANNELS, MULTI_SPLIT_TIME = 0x10000, 0x20000
 MI_OK, MI_ERR_ARG, MI_ERR_FILTER, MI_ERR_DEVICE, MI_ERR_SIZE = range(5)
 
 
@@ -434,11 +434,13 @@ class MultiEngine:
     per slot, no exchange between devices (mi_multi_*)."""
 
     def __init__(self, json_path, devices, streams: int, channels: int, in_fmt: int = PCM_S32, out_fmt: int = PCM_S32,
-                 flags: int = LOAD_DEFAULT, split_channels: bool = False):
+                 flags: int = LOAD_DEFAULT, split_channels: bool = False, split_time: bool = False):
         """split_channels: cut every stream's channels into len(devices) contiguous groups instead of dealing whole
-        streams (MI_MULTI_SPLIT_CHANNELS)."""
+        streams (MI_MULTI_SPLIT_CHANNELS); split_time: cut every stream's blocks into contiguous ranges (MI_MULTI_SPLIT_TIME)."""
         if split_channels:
             flags |= MULTI_SPLIT_CHANNELS
+        if split_time:
+            flags |= MULTI_SPLIT_TIME
         self.devices = list(devices)
         self.streams, self.channels, self.in_fmt, self.out_fmt = streams, channels, in_fmt, out_fmt
         h = C.c_void_p()

@@ -534,9 +534,14 @@ int mi_multi_create(const char *json_path, int flags, const int *devices, size_t
         if (!miups::ReadFilter(json_path, &config, &taps, &error)) {
           return Fail(MI_ERR_FILTER, error, err, errcap);
         }
-        const int split = (flags & MI_MULTI_SPLIT_CHANNELS) ? miups::kSplitChannels : miups::kSplitStreams;
+        if ((flags & MI_MULTI_SPLIT_CHANNELS) && (flags & MI_MULTI_SPLIT_TIME)) {
+          return Fail(MI_ERR_ARG, "MI_MULTI_SPLIT_CHANNELS and MI_MULTI_SPLIT_TIME exclude each other", err, errcap);
+        }
+        const int split = (flags & MI_MULTI_SPLIT_CHANNELS) ? miups::kSplitChannels
+                                                            : ((flags & MI_MULTI_SPLIT_TIME) ? miups::kSplitTime : miups::kSplitStreams);
         auto m = miups::MultiEngine::Create(std::vector<int>(devices, devices + n_devices), config, taps,
-                                            flags & ~MI_MULTI_SPLIT_CHANNELS, streams, channels, in_fmt, out_fmt, &error, split);
+                                            flags & ~(MI_MULTI_SPLIT_CHANNELS | MI_MULTI_SPLIT_TIME), streams, channels, in_fmt,
+                                            out_fmt, &error, split);
         if (!m) {
           return Fail(MI_ERR_DEVICE, error, err, errcap);
         }

@@ -277,6 +277,12 @@ struct IoDesc {
   // split form (fused_split_kernel): a staging plane holds the (y[4m], y[4m+1]) pairs in its
   // first half and the (y[4m+2], y[4m+3]) pairs in its second half (m >= Oc/4, Oc % 4 == 0)
   int split_planes;
+  // split form: where a workgroup parks the first-pass inputs of a phase's SECOND half transform while the first one
+  // runs ([workgroup][16 slots][T] + [17] self lanes, 16 bytes each = kSplitParkWords f4 per workgroup); null = the
+  // second half recomputes its spectral products (the round-2 form)
+  f4 *park;
 };
+// f4 words per workgroup of IoDesc::park for a split kernel of T threads
+MI_HD constexpr int split_park_words(int threads) { return 16 * threads + 32; }
 
 }  // namespace miups

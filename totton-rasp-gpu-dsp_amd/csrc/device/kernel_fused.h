@@ -1155,6 +1155,18 @@ struct FusedKernel {
       om = cneg(cmul(csub(zk2, zkm1), w));
     }
   }
+  // both halves at once: the pair products are the same, only the last combination differs
+  static MI_DEVICE void quad_phase_both(cf x1a, cf x1b, cf x2a, cf x2b, cf W1, f4 g1, f4 g2, cf &ok0, cf &om0, cf &ok1,
+                                        cf &om1) {
+    cf zk1, zkm1, zk2, zkm2;
+    pair_phase(x1a, x1b, W1, g1, zk1, zkm1);                        // Z'[k], Z'[2K-k]
+    pair_phase(x2a, x2b, cneg(cmulj(cconj(W1))), g2, zk2, zkm2);    // Z'[K-k], Z'[K+k]
+    ok0 = cadd(zk1, zkm2);
+    om0 = cadd(zk2, zkm1);
+    const cf w = cmul(W1, W1);
+    ok1 = cmulc(csub(zk1, zkm2), w);
+    om1 = cneg(cmul(csub(zk2, zkm1), w));
+  }
   static MI_DEVICE void split_spectrum2(const cf *EA, const cf *EB, const cf *OA, const cf *OB, cf Wa, cf *X1a, cf *X1b,
                                         cf *X2a, cf *X2b) {
     MI_UNROLL
@@ -1227,6 +1239,83 @@ struct FusedKernel {
       quad_phase<H>(Xs[0], Xs[1], Xs[2], Xs[3], Ws, g0[tid], g0[kSelfLanes + tid], ok, om);
       lds[sl.posK] = ok;
       lds[sl.posM] = om;  // lanes 0 and 8: the same word, the same value
+    }
+  }
+
+  // The same stage for BOTH half transforms of a phase in one go (IoDesc::park != null): the pair products of the two
+  // halves are identical, only the last combination differs, so the second half's first-pass inputs are formed here
+  // too and parked in global memory ([slot][T] words of 16 bytes, lane-contiguous; 128 KB per workgroup, rewritten every
+  // phase, so it lives in L2 / Infinity Cache) until the first half's inverse transform has left the LDS. Round 2 recomputed
+  // the whole stage for the second half (table loads and ~1000 VALU instructions per thread again): the stage was 32 % of
+  // the split kernel (profiles/r03_d_stamps_config4_split.txt).
+  static MI_DEVICE void phase_inputs2_both(int tid, const cf *X1a, const cf *X1b, const cf *X2a, const cf *X2b, const cf *Xs,
+                                           cf Wa, cf Ws, const SelfLane &sl, const f4 *MI_RESTRICT gt,
+                                           const f4 *MI_RESTRICT g0, cf *lds, const Bfly<16, 1> &bA, const Bfly<16, 1> &bB,
+                                           f4 *MI_RESTRICT park) {
+    const f4 *pg = gt + tid;
+    f4 *pk = park + tid;
+    constexpr int GS = MIUPS_PHASE2_SLOTS, GD = MIUPS_PHASE2_DEPTH, NG = 16 / GS;
+    f4 gv[GD][2 * GS];
+    auto request = [&](int q) {
+      MI_UNROLL
+      for (int j = 0; j < GS; ++j) {
+        gv[q % GD][2 * j] = pg[(GS * q + j) * T];
+        gv[q % GD][2 * j + 1] = pg[(16 + GS * q + j) * T];
+      }
+    };
+    MI_UNROLL
+    for (int q = 0; q < GD - 1; ++q) {
+      request(q);
+    }
+    MI_UNROLL
+    for (int q = 0; q < NG; ++q) {
+      if (q + GD - 1 < NG) {
+        request(q + GD - 1);
+      }
+      MI_SCHED_FENCE();
+      MI_UNROLL
+      for (int j = 0; j < GS; ++j) {
+        const int t = GS * q + j;
+        cf ok0, om0, ok1, om1;
+        quad_phase_both(X1a[t], X1b[t], X2a[t], X2b[t], cmul(Wa, w64(t)), gv[q % GD][2 * j], gv[q % GD][2 * j + 1], ok0, om0,
+                        ok1, om1);
+        if (tid != 0) {
+          lds[bA.at(t)] = ok0;
+          lds[bB.at(15 - t)] = om0;
+        }
+        pk[t * T] = f4{ok1.x, ok1.y, om1.x, om1.y};
+      }
+      MI_SCHED_FENCE();
+    }
+    if (tid < kSelfLanes) {
+      cf ok0, om0, ok1, om1;
+      quad_phase_both(Xs[0], Xs[1], Xs[2], Xs[3], Ws, g0[tid], g0[kSelfLanes + tid], ok0, om0, ok1, om1);
+      lds[sl.posK] = ok0;
+      lds[sl.posM] = om0;  // lanes 0 and 8: the same word, the same value
+      park[16 * T + tid] = f4{ok1.x, ok1.y, om1.x, om1.y};
+    }
+  }
+  // ... and the second half's stage: its parked first-pass inputs back into the thread's own two LDS blocks
+  static MI_DEVICE void phase_inputs2_unpark(int tid, const SelfLane &sl, cf *lds, const Bfly<16, 1> &bA,
+                                             const Bfly<16, 1> &bB, const f4 *MI_RESTRICT park) {
+    const f4 *pk = park + tid;
+    f4 v[16];
+    MI_UNROLL
+    for (int t = 0; t < 16; ++t) {
+      v[t] = pk[t * T];
+    }
+    MI_SCHED_FENCE();
+    if (tid != 0) {
+      MI_UNROLL
+      for (int t = 0; t < 16; ++t) {
+        lds[bA.at(t)] = mk(v[t].x, v[t].y);
+        lds[bB.at(15 - t)] = mk(v[t].z, v[t].w);
+      }
+    }
+    if (tid < kSelfLanes) {
+      const f4 s = park[16 * T + tid];
+      lds[sl.posK] = mk(s.x, s.y);
+      lds[sl.posM] = mk(s.z, s.w);
     }
   }
 
@@ -1822,7 +1911,7 @@ struct FusedKernel {
     }
   }
   static MI_DEVICE void channel_block_split(const Geometry &g, const IoDesc &io, BlockIo b, float *scr_c,
-                                            const FusedTables &ft, cf *lds, int tid, int cc) {
+                                            const FusedTables &ft, cf *lds, int tid, int cc, f4 *park) {
     constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
     const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
     (void)sb;
@@ -1880,7 +1969,13 @@ struct FusedKernel {
       MI_OPAQUE_VGPR(ba);
       MI_OPAQUE_VGPR(bb);
       const Bfly<16, 1> bfA(ba), bfB(bb);
-      if (h == 0) {
+      if (park != nullptr) {
+        if (h == 0) {
+          phase_inputs2_both(tl, X1a, X1b, X2a, X2b, Xs, Wa, Ws, sl, gt, g0, lds, bfA, bfB, park);
+        } else {
+          phase_inputs2_unpark(tl, sl, lds, bfA, bfB, park);
+        }
+      } else if (h == 0) {
         phase_inputs2<0>(tl, X1a, X1b, X2a, X2b, Xs, Wa, Ws, sl, gt, g0, lds, bfA, bfB);
       } else {
         phase_inputs2<1>(tl, X1a, X1b, X2a, X2b, Xs, Wa, Ws, sl, gt, g0, lds, bfA, bfB);
@@ -1962,7 +2057,8 @@ struct FusedKernel {
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
       if constexpr (SPLIT) {
-        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc);
+        f4 *park = io.park ? io.park + static_cast<long long>(local) * split_park_words(T) : nullptr;
+        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, park);
       } else {
         channel_block<EXT>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc);
       }

@@ -105,6 +105,11 @@ class Engine {
   static std::unique_ptr<Engine> Create(std::shared_ptr<DeviceFilter> filter, int streams, int channels, int inFmt,
                                         int outFmt, std::string *error);
   std::unique_ptr<Engine> Clone(std::string *error);  // deep copy of the history (after everything enqueued so far)
+  // Replace the carried history by the caller's: for every stream the last hist_frames() input frames before the next
+  // block, interleaved PCM in the engine's input format, stream s at h + s*streamStride (host memory). What a
+  // time-sharded caller (MultiEngine, kSplitTime) needs: a shard's left context is input, never output.
+  bool LoadHistoryHost(const void *h, std::size_t streamStride, std::string *error);
+  std::size_t histFrames() const { return static_cast<std::size_t>(filter_->geometry().hist_frames); }
   // Switch to another filter of the SAME geometry class between blocks (rate-family / phase switching with resident
   // spectra, EQ forks). The history is input-domain, so it carries over when the history length matches; otherwise
   // (or with resetHistory) it is zeroed, as after LoadFilter in the reference.
@@ -166,6 +171,8 @@ class Engine {
   std::size_t scratchBytes_ = 0;
   float *planar_ = nullptr;        // fused path, > 2 channels: per-channel fp32 timelines (planarize_kernel)
   std::size_t planarBytes_ = 0;
+  void *park_ = nullptr;           // split form: parked first-pass inputs of the second half transforms (IoDesc::park)
+  std::size_t parkBytes_ = 0;
   void *hist_[2] = {nullptr, nullptr};
   int cur_ = 0;
   std::size_t histStride_ = 0;  // bytes per stream

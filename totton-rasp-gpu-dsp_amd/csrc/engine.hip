@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <initializer_list>
 #include <cstring>
@@ -581,6 +582,7 @@ Engine::~Engine() {
   }
   (void)hipFree(scratch_);
   (void)hipFree(planar_);
+  (void)hipFree(park_);
   for (void *e : eventPool_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -769,6 +771,32 @@ bool Engine::Reset(std::string *error) {
   MI_HIP(hipMemsetAsync(hist_[0], 0, bytes, own));
   MI_HIP(hipMemsetAsync(hist_[1], 0, bytes, own));
   return MarkDone(own_, nullptr, error);
+}
+
+bool Engine::LoadHistoryHost(const void *h, std::size_t streamStride, std::string *error) {
+  if (!h || streamStride < histStride_) {
+    if (error) {
+      *error = "history buffer missing or stream stride smaller than one stream's history";
+    }
+    return false;
+  }
+  if (!UseDevice(filter_->device(), error)) {
+    return false;
+  }
+  hipStream_t own = static_cast<hipStream_t>(own_);
+  if (!OrderAfterLast(own_, error)) {
+    return false;
+  }
+  for (int s = 0; s < streams_ && histStride_ > 0; ++s) {
+    MI_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_]) + static_cast<std::size_t>(s) * histStride_,
+                          static_cast<const char *>(h) + static_cast<std::size_t>(s) * streamStride, histStride_,
+                          hipMemcpyHostToDevice, own));
+  }
+  if (!MarkDone(own_, nullptr, error)) {
+    return false;
+  }
+  // the caller may reuse (or change) its buffer when this returns
+  return HipOk(hipStreamSynchronize(own), "hipStreamSynchronize(history)", error);
 }
 
 bool Engine::Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std::string *error) {
@@ -1072,6 +1100,21 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     }
     ioF.ext_epilogue = ext ? 1 : 0;
     ioF.split_planes = split ? 1 : 0;
+    ioF.park = nullptr;
+    if (split && std::getenv("MIUPS_EXP_PARK") != nullptr) {  // experiment switch (profiles/r03_g_split_park.txt): measured 0.89x
+      // the second half transform of a phase takes its first-pass inputs from here (kernel_fused.h phase_inputs2_both)
+      const std::size_t words = static_cast<std::size_t>(split_park_words(g.K / 64));  // T = (K/2) / 32 threads
+      const std::size_t need = std::min<std::size_t>(chunk, pairs) * groups_ * words * sizeof(f4);
+      if (need > parkBytes_) {
+        Reap(true);
+        (void)hipFree(park_);
+        park_ = nullptr;
+        parkBytes_ = 0;
+        MI_HIP(hipMalloc(reinterpret_cast<void **>(&park_), need));
+        parkBytes_ = need;
+      }
+      ioF.park = static_cast<f4 *>(park_);
+    }
     const bool quad = ioF.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 &&
                       g.Bc % 4 == 0;
     hipStream_t aux = static_cast<hipStream_t>(aux_);
@@ -1257,6 +1300,15 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     return false;
   }
   const bool pitchedIn = inFramePitch > inFrame, pitchedOut = outFramePitch > outFrame;
+  // Pitched DMA only for rows the copy engines take whole dwords of: a column group of odd byte width (one s16 channel,
+  // packed 24-bit samples) is packed / unpacked on the host instead -- correct, synchronous and slow; the runtime aborted
+  // in hipMemcpy2DAsync on 2-byte rows out of hipHostRegister'ed memory (gpurun_out/r03g, recorded in profiles/r03_g_*).
+  auto dwordRows = [](const void *base, std::size_t stride, std::size_t pitch, std::size_t width) {
+    return reinterpret_cast<std::uintptr_t>(base) % 4 == 0 && stride % 4 == 0 && pitch % 4 == 0 && width % 4 == 0;
+  };
+  const bool packIn = pitchedIn && !dwordRows(hIn, inStride, inFramePitch, inFrame);
+  const bool packOut = pitchedOut && !dwordRows(hOut, outStride, outFramePitch, outFrame);
+  std::vector<char> hostRows;  // the fallback's packed rows of one stream and sub-batch
   // bytes one block takes in the CALLER's buffers
   const std::size_t inBlockHost = pitchedIn ? static_cast<std::size_t>(g.n_in) * inFramePitch : inBlock;
   const std::size_t outBlockHost = pitchedOut ? static_cast<std::size_t>(g.B) * outFramePitch : outBlock;
@@ -1305,8 +1357,19 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     if (j >= 2) {
       MI_HIP(hipStreamWaitEvent(h2d, evRun, 0));  // the kernels of j-2 have read this input slot
     }
+    if (packIn && j >= 2) {
+      MI_HIP(hipEventSynchronize(evRun));  // the kernels of j-2 have read this input slot (the copy below is synchronous)
+    }
     for (int s = 0; s < streams_; ++s) {
-      if (pitchedIn) {
+      if (packIn) {
+        const std::size_t rows = nb * static_cast<std::size_t>(g.n_in);
+        hostRows.resize(rows * inFrame);
+        const char *src = static_cast<const char *>(hIn) + s * inStride + b0 * inBlockHost;
+        for (std::size_t f = 0; f < rows; ++f) {
+          std::memcpy(hostRows.data() + f * inFrame, src + f * inFramePitch, inFrame);
+        }
+        MI_HIP(hipMemcpy(static_cast<char *>(stageIn_[slot]) + s * inRow, hostRows.data(), rows * inFrame, hipMemcpyHostToDevice));
+      } else if (pitchedIn) {
         MI_HIP(hipMemcpy2DAsync(static_cast<char *>(stageIn_[slot]) + s * inRow, inFrame,
                                 static_cast<const char *>(hIn) + s * inStride + b0 * inBlockHost, inFramePitch, inFrame,
                                 nb * static_cast<std::size_t>(g.n_in), hipMemcpyHostToDevice, h2d));
@@ -1329,8 +1392,20 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     }
     MI_HIP(hipEventRecord(evRun, own));
     MI_HIP(hipStreamWaitEvent(d2h, evRun, 0));
+    if (packOut) {
+      MI_HIP(hipEventSynchronize(evRun));  // kernels done: the synchronous copies below may read the output slot
+    }
     for (int s = 0; s < streams_; ++s) {
-      if (pitchedOut) {
+      if (packOut) {
+        const std::size_t rows = nb * static_cast<std::size_t>(g.B);
+        hostRows.resize(rows * outFrame);
+        MI_HIP(hipMemcpy(hostRows.data(), static_cast<const char *>(stageOut_[slot]) + s * outRow, rows * outFrame,
+                         hipMemcpyDeviceToHost));
+        char *dst = static_cast<char *>(hOut) + s * outStride + b0 * outBlockHost;
+        for (std::size_t f = 0; f < rows; ++f) {
+          std::memcpy(dst + f * outFramePitch, hostRows.data() + f * outFrame, outFrame);
+        }
+      } else if (pitchedOut) {
         MI_HIP(hipMemcpy2DAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlockHost, outFramePitch,
                                 static_cast<const char *>(stageOut_[slot]) + s * outRow, outFrame, outFrame,
                                 nb * static_cast<std::size_t>(g.B), hipMemcpyDeviceToHost, d2h));
@@ -1378,26 +1453,31 @@ void HostUnregister(void *p) {
 }
 
 namespace {
-// four independent 16-byte loads per lane in flight, then four stores; a workgroup walks whole 16 KiB pieces
+// Copy kernels for the measured ceiling. U independent 16-byte loads per lane in flight, then U stores. kPersist: a grid of
+// 8 workgroups per CU walks the buffer; else one short-lived workgroup per 256 * U * 16-byte piece (the shape of this
+// library's own frame-assembly pass). DeviceCopyRate reports the best of the forms (profiles/r03_h_copy_forms.txt).
+template <int U, bool kPersist>
 __global__ void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, std::size_t n) {
-  const std::size_t piece = static_cast<std::size_t>(blockDim.x) * 4;
-  const std::size_t stride = static_cast<std::size_t>(gridDim.x) * piece;
+  const std::size_t piece = static_cast<std::size_t>(256) * U;
+  const std::size_t stride = kPersist ? static_cast<std::size_t>(gridDim.x) * piece : n;
   for (std::size_t base = static_cast<std::size_t>(blockIdx.x) * piece; base < n; base += stride) {
-    const std::size_t i = base + threadIdx.x;
-    uint4 v[4];
+    uint4 v[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const std::size_t j = i + static_cast<std::size_t>(k) * blockDim.x;
+    for (int k = 0; k < U; ++k) {
+      const std::size_t j = base + threadIdx.x + static_cast<std::size_t>(k) * 256;
       if (j < n) {
         v[k] = src[j];
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const std::size_t j = i + static_cast<std::size_t>(k) * blockDim.x;
+    for (int k = 0; k < U; ++k) {
+      const std::size_t j = base + threadIdx.x + static_cast<std::size_t>(k) * 256;
       if (j < n) {
         dst[j] = v[k];
       }
+    }
+    if (!kPersist) {
+      break;
     }
   }
 }
@@ -1422,20 +1502,31 @@ bool DeviceCopyRate(int device, std::size_t bytes, int iters, double *gbps, std:
   double best = 0.0;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  for (int i = 0; ok && i < iters + 1; ++i) {  // the first launch is a warm-up
-    ok = HipOk(hipEventRecord(e0, nullptr), "hipEventRecord", error);
-    int perCu = 8;
-    if (const char *v = std::getenv("MIUPS_EXP_COPY_BLOCKS_PER_CU")) {  // experiment switch (profiles/r03_f_*)
-      perCu = std::max(1, std::atoi(v));
-    }
-    hipLaunchKernelGGL(copy16_kernel, dim3(static_cast<unsigned>(cus) * perCu), dim3(256), 0, nullptr,
-                       static_cast<const uint4 *>(a), static_cast<uint4 *>(b), n);
-    ok = ok && HipOk(hipEventRecord(e1, nullptr), "hipEventRecord", error) &&
-         HipOk(hipEventSynchronize(e1), "hipEventSynchronize", error);
-    float ms = 0.0f;
-    ok = ok && HipOk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime", error);
-    if (ok && i > 0 && ms > 0.0f) {
-      best = std::max(best, 2.0 * static_cast<double>(n) * 16.0 / (static_cast<double>(ms) * 1e-3) / 1e9);
+  const unsigned persist = static_cast<unsigned>(cus) * 8;
+  auto pieces = [&](int u) { return static_cast<unsigned>((n + 256u * u - 1) / (256u * u)); };
+  for (int form = 0; ok && form < 5; ++form) {
+    for (int i = 0; ok && i < iters + 1; ++i) {  // the first launch of a form is a warm-up
+      ok = HipOk(hipEventRecord(e0, nullptr), "hipEventRecord", error);
+      const uint4 *src = static_cast<const uint4 *>(a);
+      uint4 *dst = static_cast<uint4 *>(b);
+      switch (form) {
+        case 0: hipLaunchKernelGGL((copy16_kernel<1, true>), dim3(persist), dim3(256), 0, nullptr, src, dst, n); break;
+        case 1: hipLaunchKernelGGL((copy16_kernel<4, true>), dim3(persist), dim3(256), 0, nullptr, src, dst, n); break;
+        case 2: hipLaunchKernelGGL((copy16_kernel<4, false>), dim3(pieces(4)), dim3(256), 0, nullptr, src, dst, n); break;
+        case 3: hipLaunchKernelGGL((copy16_kernel<8, false>), dim3(pieces(8)), dim3(256), 0, nullptr, src, dst, n); break;
+        default: hipLaunchKernelGGL((copy16_kernel<2, false>), dim3(pieces(2)), dim3(256), 0, nullptr, src, dst, n); break;
+      }
+      ok = ok && HipOk(hipEventRecord(e1, nullptr), "hipEventRecord", error) &&
+           HipOk(hipEventSynchronize(e1), "hipEventSynchronize", error);
+      float ms = 0.0f;
+      ok = ok && HipOk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime", error);
+      if (ok && i > 0 && ms > 0.0f) {
+        const double rate = 2.0 * static_cast<double>(n) * 16.0 / (static_cast<double>(ms) * 1e-3) / 1e9;
+        best = std::max(best, rate);
+        if (std::getenv("MIUPS_EXP_COPY_VERBOSE")) {  // experiment switch (profiles/r03_h_copy_forms.txt)
+          std::fprintf(stderr, "copy form %d: %.1f GB/s\n", form, rate);
+        }
+      }
     }
   }
   (void)hipEventDestroy(e0);

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 
 namespace miups {
@@ -111,7 +112,7 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
     }
     return nullptr;
   }
-  if (split != kSplitStreams && split != kSplitChannels) {
+  if (split != kSplitStreams && split != kSplitChannels && split != kSplitTime) {
     if (error) {
       *error = "unknown partition";
     }
@@ -143,6 +144,10 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
       s->streams = streams;
       s->c0 = groups[static_cast<std::size_t>(i)];
       s->nch = groups[static_cast<std::size_t>(i) + 1] - s->c0;
+    } else if (split == kSplitTime) {
+      s->streams = streams;  // every slot sees every stream, a block range of it
+      s->c0 = 0;
+      s->nch = channels;
     } else {
       s->streams = std::max(0, (streams - i + G - 1) / G);  // streams i, i+G, i+2G, ...
       s->c0 = 0;
@@ -161,6 +166,13 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
       }
     }
     m->slots_.push_back(std::move(s));
+  }
+  if (split == kSplitTime) {
+    m->histBytes_ = m->slots_[0]->engine->histFrames() * static_cast<std::size_t>(channels) * pcm_bytes(inFmt);
+    m->tail_.assign(m->histBytes_ * static_cast<std::size_t>(streams), 0);
+    for (auto &s : m->slots_) {
+      s->context.assign(m->tail_.size(), 0);
+    }
   }
   for (auto &s : m->slots_) {
     s->worker = std::thread(&MultiEngine::WorkerMain, m.get(), s.get());
@@ -207,7 +219,32 @@ void MultiEngine::WorkerMain(Slot *slot) {
     std::string err;
     if (slot->engine) {
       const std::size_t G = slots_.size();
-      if (split_ == kSplitChannels) {
+      if (split_ == kSplitTime) {
+        // blocks [b0, b1) of every stream; the hist_frames input frames in front of b0 come from the caller's buffer and,
+        // where the range starts less than that into the call, from the tail kept of the previous call
+        const std::size_t b0 = job.blocks * static_cast<std::size_t>(slot->index) / G;
+        const std::size_t b1 = job.blocks * (static_cast<std::size_t>(slot->index) + 1) / G;
+        if (b1 > b0) {
+          const Geometry &g = geometry();
+          const std::size_t frameIn = static_cast<std::size_t>(channels_) * pcm_bytes(inFmt_);
+          const std::size_t frameOut = static_cast<std::size_t>(channels_) * pcm_bytes(outFmt_);
+          const std::size_t startBytes = b0 * static_cast<std::size_t>(g.n_in) * frameIn;  // of the range, inside the call
+          for (int st = 0; st < streams_ && histBytes_ > 0; ++st) {
+            char *dst = slot->context.data() + static_cast<std::size_t>(st) * histBytes_;
+            const char *in = static_cast<const char *>(job.hIn) + static_cast<std::size_t>(st) * job.inStride;
+            const std::size_t fromCall = std::min(startBytes, histBytes_);   // newest part: the call's own frames
+            const std::size_t fromTail = histBytes_ - fromCall;              // oldest part: end of the previous call's tail
+            if (fromTail) {
+              std::memcpy(dst, tail_.data() + static_cast<std::size_t>(st) * histBytes_ + fromCall, fromTail);
+            }
+            std::memcpy(dst + fromTail, in + startBytes - fromCall, fromCall);
+          }
+          ok = (histBytes_ == 0 || slot->engine->LoadHistoryHost(slot->context.data(), histBytes_, &err)) &&
+               slot->engine->ProcessHost(static_cast<const char *>(job.hIn) + startBytes, job.inStride,
+                                         static_cast<char *>(job.hOut) + b0 * static_cast<std::size_t>(g.B) * frameOut,
+                                         job.outStride, b1 - b0, &err);
+        }
+      } else if (split_ == kSplitChannels) {
         // this slot's channel group: a column of the caller's frames -- pitched copies, no gather on the host
         const std::size_t ib = static_cast<std::size_t>(pcm_bytes(inFmt_)), ob = static_cast<std::size_t>(pcm_bytes(outFmt_));
         ok = slot->engine->ProcessHost(static_cast<const char *>(job.hIn) + static_cast<std::size_t>(slot->c0) * ib,
@@ -264,6 +301,20 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
   cvJob_.notify_all();
   std::unique_lock<std::mutex> lock(mu_);
   cvDone_.wait(lock, [&] { return pending_ == 0; });
+  if (split_ == kSplitTime && histBytes_ > 0) {
+    // what the next call's first ranges will need: the last hist_frames input frames of (tail ++ this call) per stream
+    const std::size_t callBytes = blocks * static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
+    for (int st = 0; st < streams_; ++st) {
+      char *t = tail_.data() + static_cast<std::size_t>(st) * histBytes_;
+      const char *in = static_cast<const char *>(hIn) + static_cast<std::size_t>(st) * inStride;
+      if (callBytes >= histBytes_) {
+        std::memcpy(t, in + callBytes - histBytes_, histBytes_);
+      } else {
+        std::memmove(t, t + callBytes, histBytes_ - callBytes);
+        std::memcpy(t + histBytes_ - callBytes, in, callBytes);
+      }
+    }
+  }
   for (auto &s : slots_) {
     if (!s->ok) {
       if (error) {
@@ -300,6 +351,7 @@ bool MultiEngine::SetEq(const std::string &apoText, double fsOut, std::string *e
 }
 
 bool MultiEngine::Reset(std::string *error) {
+  std::fill(tail_.begin(), tail_.end(), 0);
   for (auto &s : slots_) {
     if (s->engine && !s->engine->Reset(error)) {
       return false;

@@ -7,7 +7,14 @@
 //                   runs on slot i (ONE wide stream over several GPUs: BASELINE configs[4], "32-channel, 1->8 GPU sweep").
 //                   A slot reads and writes its column group straight out of / into the caller's interleaved frames with
 //                   pitched 2-D copies (Engine::ProcessHost frame pitches): no host de-interleave, and each device's link
-//                   carries only its own channels.
+//                   carries only its own channels. Measured (profiles/r03_h_multi_split.txt): pitched DMA moves ~180 M rows
+//                   per second, i.e. 11 / 6 / 3 GB/s for 64 / 32 / 16-byte rows against 54 GB/s contiguous -- right for
+//                   wide groups, wrong for narrow ones; hence:
+//   kSplitTime      every stream's BLOCKS are cut into G contiguous ranges, range i on slot i, all channels: the copies are
+//                   contiguous (full link rate per device) and nothing is re-laid-out. A block depends on earlier blocks
+//                   only through the INPUT history ("time-sharded"), so a slot needs the hist_frames input frames
+//                   in front of its range: they are in the caller's buffer (or, at the start of a call, in the tail this
+//                   object keeps of the previous call) and are handed to the slot's engine before it runs.
 // G = number of (device) slots; a slot owns one device, its own copy of the filter tables, the histories of its
 // units, one engine with its HIP streams and staging pipeline, and one host worker thread pinned to the CPUs local to
 // its device (sysfs local_cpulist of the device's PCI function). Nothing is shared between slots but the caller's
@@ -26,7 +33,7 @@
 
 namespace miups {
 
-enum MultiSplit : int { kSplitStreams = 0, kSplitChannels = 1 };
+enum MultiSplit : int { kSplitStreams = 0, kSplitChannels = 1, kSplitTime = 2 };
 
 // slot of every stream under the static block-cyclic partition
 std::vector<int> PartitionStreams(int streams, int slots);
@@ -70,7 +77,8 @@ class MultiEngine {
   };
   struct Slot {
     int index = 0, device = 0, streams = 0;
-    int c0 = 0, nch = 0;  // channel group (the whole frame under kSplitStreams)
+    int c0 = 0, nch = 0;  // channel group (the whole frame under kSplitStreams / kSplitTime)
+    std::vector<char> context;  // kSplitTime: the slot's left context, [stream][hist_frames] frames
     std::shared_ptr<DeviceFilter> filter;
     std::unique_ptr<Engine> engine;  // null when the slot has no unit (more slots than streams / channels)
     std::thread worker;
@@ -89,6 +97,8 @@ class MultiEngine {
   int pending_ = 0;
   bool quit_ = false;
   int failEqSlot_ = -1;
+  std::vector<char> tail_;  // kSplitTime: the last hist_frames input frames of every stream seen so far (zeros at start)
+  std::size_t histBytes_ = 0;  // ... per stream
 };
 
 }  // namespace miups

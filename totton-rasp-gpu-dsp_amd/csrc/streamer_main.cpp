@@ -54,6 +54,7 @@ struct CliOptions {
   int device = 0;
   std::vector<int> gpus;        // --gpus a,b,...: stream s runs on gpus[s mod n]
   bool splitChannels = false;   // --split channels: contiguous channel groups of every stream per GPU instead
+  bool splitTime = false;       // --split time: contiguous block ranges of every stream per GPU
   unsigned streams = 1;         // file mode: the input file holds this many equal-length streams back to back
   unsigned blocksPerCall = 16;
   std::string eqPath;
@@ -87,8 +88,9 @@ void PrintUsage(const char *argv0) {
             << "  --buffer <frames>       ALSA buffer frames (default: period*4)\n"
             << "  --device <n>            HIP device index (default: 0)\n"
             << "  --gpus <a,b,...>        HIP devices to shard independent streams over (stream s -> gpus[s mod n])\n"
-            << "  --split <streams|channels>  with --gpus: whole streams per GPU (default), or the channels of every stream\n"
-            << "                          in contiguous groups, one group per GPU (one wide stream over several GPUs)\n"
+            << "  --split <streams|channels|time>  with --gpus: whole streams per GPU (default); the channels of every stream in\n"
+            << "                          contiguous groups, one per GPU; or the blocks of every call in contiguous ranges, one\n"
+            << "                          per GPU (one wide stream over several GPUs, contiguous copies)\n"
             << "  --streams <n>           File mode: the input holds n equal-length streams back to back (default: 1)\n"
             << "  --blocks-per-call <n>   Filter blocks batched per GPU call (default: 16)\n"
             << "  --eq <path>             Equalizer-APO profile folded into the filter\n"
@@ -167,11 +169,12 @@ bool ParseArgs(int argc, char **argv, CliOptions *o) {
       }
     } else if (arg == "--split") {
       ok = value(&tmp);
-      if (ok && tmp != "streams" && tmp != "channels") {
+      if (ok && tmp != "streams" && tmp != "channels" && tmp != "time") {
         std::cerr << "Invalid value for --split: " << tmp << "\n";
         ok = false;
       }
       o->splitChannels = ok && tmp == "channels";
+      o->splitTime = ok && tmp == "time";
     } else if (arg == "--gpus") {
       ok = value(&tmp);
       std::stringstream ss(tmp);
@@ -256,7 +259,9 @@ bool PrepareFilter(const CliOptions &o, int fmt, Pipeline *p) {
   }
   mi_ups_config c;
   if (!o.gpus.empty()) {
-    if (mi_multi_create(path, MI_LOAD_DEFAULT | (o.splitChannels ? MI_MULTI_SPLIT_CHANNELS : 0), o.gpus.data(), o.gpus.size(),
+    if (mi_multi_create(path,
+                        MI_LOAD_DEFAULT | (o.splitChannels ? MI_MULTI_SPLIT_CHANNELS : 0) | (o.splitTime ? MI_MULTI_SPLIT_TIME : 0),
+                        o.gpus.data(), o.gpus.size(),
                         static_cast<int>(p->streams),
                         static_cast<int>(o.channels), fmt, fmt, &p->multi, err, sizeof(err)) != MI_OK) {
       std::cerr << "Filter load failed: " << err << "\n";
