@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC summaries of scripts/gpu_r02_measure.sh (gpurun_out/r02/pmc_<tag>.txt).
+"""profiles/traffic.json from the PMC summaries of scripts/gpu_r03_measure.sh (gpurun_out/<round>/pmc_<tag>.txt).
+usage: traffic_from_pmc.py PREFIX [SOURCE_DIR]      e.g. traffic_from_pmc.py r03_m gpurun_out/r03m
 
 HBM-side bytes per bench step = sum over the kernels of one mi_engine_process_device call of
 (2 * FETCH_SIZE + WRITE_SIZE) KiB x launches of that kernel per call. Unit of both counters: KiB. gfx950 correction per
@@ -10,8 +11,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-SRC = ROOT / "gpurun_out" / "r02"
-PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02_h"  # profiles/<PREFIX>_pmc_<tag>.txt
+PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r03_m"  # profiles/<PREFIX>_pmc_<tag>.txt
+SRC = ROOT / (sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r03m")
 TAGS = {"c2_256": ("2", 1, 2, 256), "c2_2048": ("2_2048blocks", 1, 2, 2048), "c3": ("3", 1, 8, 256), "c4": ("4", 32, 2, 32),
         "c5": ("5", 1, 32, 64)}
 
@@ -36,7 +37,9 @@ def main():
         calls = k["miups::update_history_kernel"]["FETCH_SIZE"][1]  # one per bench step
         kernels, total = {}, 0.0
         for name, c in k.items():
-            if not name.startswith("miups::") or "update_history" in name or "anonymous" in name or "FETCH_SIZE" not in c:
+            # "miups::" alone = a kernel of the anonymous namespace cut at its "(" by pmc_summary.py: the copy-ceiling kernel
+            # of the bench line (mi_device_copy_rate), not part of a step
+            if not name.startswith("miups::") or name == "miups::" or "update_history" in name or "anonymous" in name or "FETCH_SIZE" not in c:
                 continue
             per_call = c["FETCH_SIZE"][1] / calls
             kib = (2 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * per_call

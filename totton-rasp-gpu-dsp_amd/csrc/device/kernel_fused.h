@@ -720,9 +720,9 @@ struct FusedKernel {
     } else if constexpr (W == 1) {
       cf A[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
-      dft16<-1>(A);
-      apply_twiddles_out<-1, 16>(A, w0);
-      lds_put_dft<16, K / 16>(lds, Bfly<16, K / 16>(tid), A);
+      Tw16 ta;
+      make_twiddles16<-1>(w0, ta);
+      dft_put<-1, 16, K / 16, true>(lds, Bfly<16, K / 16>(tid), A, ta.t);
     } else {
       cf A[16], B[16];
       global_read<FMT, 16, kHist, MODE, SP>(b, tid, A);
@@ -769,11 +769,11 @@ struct FusedKernel {
     constexpr int LOG2L = (S == 16) ? 8 : 12;
     if constexpr (W == 1) {
       const Bfly<16, S> bf(tid);
-      cf V[16];
-      lds_get<16, S>(lds, bf, V);
-      dft16<-1>(V);
-      apply_twiddles_out<-1, 16>(V, load_tw<LOG2L>(tw, tid & (S - 1)));
-      lds_put_dft<16, S>(lds, bf, V);
+      cf X[16];
+      lds_get<16, S>(lds, bf, X);
+      Tw16 t16;
+      make_twiddles16<-1>(load_tw<LOG2L>(tw, tid & (S - 1)), t16);
+      dft_put<-1, 16, S, true>(lds, bf, X, t16.t);
       return;
     }
     const int qA = tid, qB = tid + T;
@@ -824,11 +824,10 @@ struct FusedKernel {
     constexpr int LOG2L = (S == 16) ? 8 : 12;
     if constexpr (W == 1) {
       const Bfly<16, S> bf(tid);
-      cf V[16];
-      lds_get<16, S>(lds, bf, V);
-      apply_twiddles<+1, 16>(V, load_tw<LOG2L>(tw, tid & (S - 1)));
-      dft16<+1>(V);
-      lds_put_dft<16, S>(lds, bf, V);
+      cf X[16];
+      lds_get<16, S>(lds, bf, X);
+      apply_twiddles<+1, 16>(X, load_tw<LOG2L>(tw, tid & (S - 1)));
+      dft_put<+1, 16, S, false>(lds, bf, X, nullptr);
       return;
     }
     const int qA = tid, qB = tid + T;
@@ -1741,8 +1740,7 @@ struct FusedKernel {
         MI_STAMP(sp + 0);
         int bk = blk;
         MI_OPAQUE_VGPR(bk);
-        dft16<+1>(V);
-        lds_put_dft<16, 1>(lds, Bfly<16, 1>(bk), V);
+        dft_put<+1, 16, 1, false>(lds, Bfly<16, 1>(bk), V, nullptr);
         MI_STAMP(sp + 1);
         MI_SYNC_PAIR();
         MI_STAMP(sp + 2);
