@@ -2079,8 +2079,15 @@ struct FusedKernel {
 // SIMD, and a lone wave issues one VALU instruction per ~5 cycles instead of one per ~2.5:
 // profiles/r02_a_ubench_valu_lds_rates.txt); the narrow form four waves per SIMD = at most 128 registers.
 // R32: the experimental pass plan (FusedCfg); the host lays the tables out for the same plan (FilterTables::fusedR32).
+// MIUPS_EXP_VGPR_CAP (experiment, profiles/r03_j_coresident.txt): cap the kernel's registers below 256 so that one low-register
+// wave of another kernel (the frame pass) fits beside two transform waves on every SIMD
+#if defined(MIUPS_EXP_VGPR_CAP) && !defined(MIUPS_HOST_EMU)
+#define MI_VGPR_CAP __attribute__((amdgpu_num_vgpr(MIUPS_EXP_VGPR_CAP)))
+#else
+#define MI_VGPR_CAP
+#endif
 template <int LOG2K, bool EXT, int W = 2, bool R32 = false>
-MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : MIUPS_WIDE_WAVES)) void fused_kernel(
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>::T), (W == 1 ? 4 : MIUPS_WIDE_WAVES)) MI_VGPR_CAP void fused_kernel(
     Geometry g, IoDesc io, FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
   FusedKernel<LOG2K, W, R32>::template run<false, EXT>(g, io, ft, lds);

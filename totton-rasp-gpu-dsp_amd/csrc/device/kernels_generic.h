@@ -414,8 +414,13 @@ MI_GLOBAL void interleave_rows_kernel(Geometry g, IoDesc io, const float *MI_RES
 // tile crosses through LDS ([R][TI + 1] floats, rows in output order r = p*C + c), and every store instruction writes
 // whole frames (R*4 contiguous bytes per i) as 16-byte lane-contiguous vectors. All of a thread's loads are in flight
 // before its first LDS write.
+#if defined(MIUPS_EXP_ILV_VGPR_CAP) && !defined(MIUPS_HOST_EMU)  // experiment (profiles/r03_j_coresident.txt)
+#define MI_ILV_VGPR_CAP __attribute__((amdgpu_num_vgpr(MIUPS_EXP_ILV_VGPR_CAP)))
+#else
+#define MI_ILV_VGPR_CAP
+#endif
 template <int FMT, int TI, int EPT>
-MI_GLOBAL void interleave_tiled_kernel(Geometry g, IoDesc io, const float *MI_RESTRICT planes, int sb0, int nb,
+MI_GLOBAL MI_ILV_VGPR_CAP void interleave_tiled_kernel(Geometry g, IoDesc io, const float *MI_RESTRICT planes, int sb0, int nb,
                                        int tiles_per_pair) {
   MI_DYN_SHARED(float, tile);
   constexpr int LD = TI + 1, Q = TI / 4;  // row pitch, 16-byte words per row
