@@ -265,7 +265,10 @@ class Workload:
         """W untimed steps, then K (or at least min_seconds of) timed steps. Returns (steps done, elapsed s, kernel stats)."""
         for _ in range(warmup):
             self.eng.process_device(self.d_in, self.d_out, self.blocks, self.stream)
-        self.eng.enable_kernel_timing(64 if min_seconds else max(steps, 1))
+        # an event pair costs about 8 us of stream time (profiles/r03_n_step_overhead.txt: 131.3 us per headline step with a
+        # pair on every launch, 122.9 without any): the timed region samples every 4th launch, never fewer than 5 of them
+        self.timing_every = max(1, min(4, steps // 5))
+        self.eng.enable_kernel_timing(64 if min_seconds else max(steps, 1), self.timing_every)
         self.hip.sync()
         barrier()
         t0 = time.perf_counter()
@@ -370,6 +373,7 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
     roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms_avg": round(kstat["avg"], 5),
             "kernel_ms_min": round(kstat["min"], 5), "kernel_launches_timed": kstat["count"],
+            "timed_every_nth_launch": getattr(w, "timing_every", 1),
             "algorithmic_bytes_per_launch": int(bytes_launch)}
     key = str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks"
     rec = (traffic or {}).get(key)

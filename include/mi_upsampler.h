@@ -133,6 +133,10 @@ size_t mi_engine_in_frames_per_block(const mi_engine *e);
 size_t mi_engine_out_frames_per_block(const mi_engine *e);
 /* which kernel family the geometry selected: "fused" or "staged" */
 const char *mi_engine_path(const mi_engine *e);
+/* Small calls (fewer channel-blocks than CUs / 2) on the fused path split every channel-block's P output phases over
+ * several workgroups (each repeats the forward transform): returns that count for the latest call, 0 = not split.
+ * The reference's own call shape, one channel-block per call, takes P workgroups instead of one. */
+int mi_engine_last_phase_parts(const mi_engine *e);
 
 /* Process `blocks` consecutive blocks of every stream. d_in / d_out are DEVICE
  * pointers: stream s starts at base + s*stride bytes and holds interleaved
@@ -180,6 +184,9 @@ void mi_debug_fail_next_table_upload(mi_filter *f);
  * `slots` pairs; 0 disables). last_kernel_ms waits for the latest call;
  * kernel_ms_stats waits for and averages every recorded call. */
 int mi_engine_enable_kernel_timing(mi_engine *e, int slots);
+/* Only every `every`-th process call carries the pair (default 1 = each call). An event pair costs about 8 us of stream
+ * time (profiles/r03_n_step_overhead.txt): a timed region samples instead of paying that on every call. */
+int mi_engine_set_kernel_timing_stride(mi_engine *e, int every);
 double mi_engine_last_kernel_ms(mi_engine *e);
 int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double *max_ms, int *count);
 /* Per kernel class of the latest call (diagnostic, off by default): out4 = ms of [0] planarize, [1] transform,

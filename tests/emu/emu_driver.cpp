@@ -156,6 +156,14 @@ void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsign
       return;
     }
   }
+  if (io.phase_parts > 1) {  // small-call form (EMU_PARTS): `items` counts workgroups = work items * phase_parts
+    if constexpr (LOG2K >= kPartsMinLog2K) {
+      miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_parts_kernel<LOG2K>(g, io, ft); });
+      return;
+    }
+    std::fprintf(stderr, "EMU_PARTS: no phase-split kernel for this transform length\n");
+    std::exit(2);
+  }
   if (io.ext_epilogue) {
     miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 2, false>(g, io, ft); });
   } else {
@@ -317,8 +325,18 @@ int main(int argc, char **argv) {
           cg = v;
         }
       }
+      // EMU_PARTS=d: the engine's small-call form -- d workgroups per (block, stream, channel), P / d phases each
+      int parts = 0;
+      if (const char *pp = std::getenv("EMU_PARTS")) {
+        parts = std::atoi(pp);
+        if (parts < 2 || g.P % parts != 0 || t.fusedSplit || t.fusedNarrow || t.fusedR32) {
+          std::fprintf(stderr, "EMU_PARTS: %d does not fit this geometry\n", parts);
+          return 2;
+        }
+        cg = 1;
+      }
       // EMU_INKERNEL=1: keep the in-kernel epilogue for groups narrower than a frame
-      const bool ext = t.fusedSplit || (cg < channels && !std::getenv("EMU_INKERNEL"));
+      const bool ext = t.fusedSplit || parts > 0 || (cg < channels && !std::getenv("EMU_INKERNEL"));
       const unsigned groups = static_cast<unsigned>(channels / cg);
       const unsigned pairs = static_cast<unsigned>(blocks) * streams;
       const unsigned chunk = pairs > 1 ? (pairs + 1) / 2 : pairs;  // exercise the chunked launch (item0 > 0)
@@ -353,6 +371,7 @@ int main(int argc, char **argv) {
         ioF.in_stream_stride = ioF.in_plane_stride * channels;
       }
       ioF.ext_epilogue = ext ? 1 : 0;
+      ioF.phase_parts = parts;
       ioF.split_planes = t.fusedSplit ? 1 : 0;
       std::vector<f4> park;
       ioF.park = nullptr;
@@ -364,7 +383,7 @@ int main(int argc, char **argv) {
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);
         ioF.item0 = static_cast<int>(p0 * groups);
-        DispatchFused(g, ioF, t, np * groups);
+        DispatchFused(g, ioF, t, np * groups * static_cast<unsigned>(parts ? parts : 1));
         if (!ext) {
           continue;
         }

@@ -103,6 +103,40 @@ def test_emulated_pruned_last_pass(emu, O, make_filter, tmp_path, fft, taps, L, 
     test_emulated_kernels_match_truth(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls)
 
 
+PARTS_CASES = [  # the engine's small-call form: EMU_PARTS workgroups per (block, stream, channel), P / parts phases each
+    # fft, taps, L, parts, streams, channels, blocks, calls      (K = fft / 2L >= 1024: fused_parts_kernel exists)
+    (8192, 2049, 4, 4, 1, 1, 1, 2),    # K = 1024, mono, one phase per workgroup (the reference's call shape)
+    (8192, 5121, 4, 2, 1, 2, 2, 2),    # stereo out of 16-byte frame loads, two phases per workgroup, pruned last pass
+    (32768, 8193, 16, 8, 2, 3, 1, 1),  # K = 1024, P = 16, planar input (3 channels), two streams
+    (16384, 4099, 2, 2, 1, 2, 1, 2),   # K = 4096, odd history length (Oc = 2049)
+]
+
+
+@pytest.mark.parametrize("fft,taps,L,parts,streams,channels,blocks,calls", PARTS_CASES)
+def test_emulated_phase_split_small_calls(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, parts, streams, channels,
+                                          blocks, calls):
+    """fused_parts_kernel (kernel_fused.h run<..., PARTS>): bit-identical to the plain form with the same channel group
+    width and external epilogue (EMU_CG=1), and both against fp64 truth."""
+    rng = np.random.default_rng(fft + L + parts)
+    h = rng.standard_normal(taps).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    x = rng.standard_normal((calls, streams, blocks * nin, channels)).astype(np.float32)
+    monkeypatch.setenv("EMU_PARTS", str(parts))
+    split = run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, calls, "fused")
+    monkeypatch.delenv("EMU_PARTS")
+    plain = run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, calls, "fused")
+    assert split == plain
+    y = np.frombuffer(split, np.float32).reshape(calls, streams, blocks * block, channels)
+    for s_ in range(streams):
+        for c in range(channels):
+            xs = np.concatenate([x[k, s_, :, c] for k in range(calls)])
+            truth = O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1)
+            got = np.concatenate([y[k, s_, :, c] for k in range(calls)])
+            assert np.abs(got - truth).max() <= 1e-5 * np.abs(truth).max()
+
+
 @pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", R32_CASES)
 def test_emulated_radix32_plan(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, path, streams, channels, blocks,
                                calls):

@@ -112,9 +112,9 @@ def synthetic_filter(make_filter, fft, taps, L, seed):
     return h, make_filter(h, fft, fft - (taps - 1), L, name=f"syn{fft}_{L}")
 
 
-def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2):
+def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2, want_parts=None):
     """`calls` consecutive device calls over the same buffers (the second starts from carried history); returns both
-    outputs, int32 [call][stream][frame][channel]."""
+    outputs, int32 [call][stream][frame][channel]. want_parts: what Engine.last_phase_parts must say after a call."""
     eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
     in_stride, out_stride = eng.in_bytes(blocks), eng.out_bytes(blocks)
     d_in, d_out = hip.malloc(in_stride * streams), hip.malloc(out_stride * streams)
@@ -123,6 +123,8 @@ def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2):
         hip.h2d(d_in, pcm[k])
         eng.process_device(d_in, d_out, blocks)
         hip.sync()
+        if want_parts is not None:
+            assert eng.last_phase_parts == want_parts
         o = np.empty(out_stride * streams // 4, dtype="<i4")
         hip.d2h(o, d_out)
         outs.append(o.reshape(streams, -1, channels))
@@ -183,6 +185,36 @@ def test_forced_serial_chunks(ups, O, hip, gpu, monkeypatch, fname, streams, cha
     np.testing.assert_array_equal(chunked, one)
     x = np.concatenate(pcm, axis=1).astype(np.float64) / 2147483648.0
     y = np.concatenate(list(chunked), axis=1).astype(np.float64) / 2147483648.0
+    for s, c in ((0, 0), (streams - 1, channels - 1)):
+        want = np.clip(O.truth_stream(x[s, :, c], h, L, 2 * blocks, block).reshape(-1), -1.0, F32_HI)
+        assert np.abs(y[s, :, c] - want).max() <= 2.0 ** -31 + 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("fname,streams,channels,blocks,parts", [
+    ("filter_44k_4x_80000_min_phase", 1, 1, 1, 4),    # the reference's call shape: 4 workgroups, one phase each (K = 16384)
+    ("filter_44k_4x_80000_min_phase", 1, 2, 3, 4),    # stereo, 6 items x 4 parts: both channels out of 16-byte frame loads
+    ("filter_48k_16x_80000_min_phase", 1, 8, 2, 16),  # P = 16, 16 items x 16 parts = 256 workgroups (K = 4096), planar input
+    ("filter_48k_8x_160000_linear_phase", 2, 3, 5, 8),  # 30 items x 8 parts; odd channel count
+    ("filter_48k_16x_80000_min_phase", 3, 2, 7, 4),   # 42 items: of P = 16's divisors 4 is the largest that fits (42 x 4 <= 256)
+])
+def test_small_calls_split_their_phases_over_workgroups(ups, O, hip, gpu, monkeypatch, fname, streams, channels, blocks, parts):
+    """Calls with far fewer work items than CUs take fused_parts_kernel (several workgroups per channel-block, P / parts
+    phases each, frames by the interleave kernel). Bit-identical to the one-workgroup-per-item route
+    (MIUPS_EXP_NO_PHASE_PARTS=1) over two calls, and against fp64 truth."""
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    h, taps, fft, block, L = O.read_filter(path)
+    filt = ups.Filter(path, device=gpu)
+    nin = block // L
+    rng = np.random.default_rng(streams * 100 + channels * 10 + blocks)
+    pcm = [(np.clip(rng.standard_normal((streams, blocks * nin, channels)) * 0.05, -1, 1) * 2147483647).astype("<i4")
+           for _ in range(2)]
+    monkeypatch.setenv("MIUPS_EXP_NO_PHASE_PARTS", "1")
+    plain = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_parts=0)
+    monkeypatch.delenv("MIUPS_EXP_NO_PHASE_PARTS")
+    split = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_parts=parts)
+    np.testing.assert_array_equal(split, plain)
+    x = np.concatenate(pcm, axis=1).astype(np.float64) / 2147483648.0
+    y = np.concatenate(list(split), axis=1).astype(np.float64) / 2147483648.0
     for s, c in ((0, 0), (streams - 1, channels - 1)):
         want = np.clip(O.truth_stream(x[s, :, c], h, L, 2 * blocks, block).reshape(-1), -1.0, F32_HI)
         assert np.abs(y[s, :, c] - want).max() <= 2.0 ** -31 + 1e-5 * np.abs(want).max()

@@ -502,6 +502,16 @@ int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double 
   return e->engine->KernelMsStats(avg, min_ms, max_ms, count) ? MI_OK : Fail(MI_ERR_DEVICE, "no timed calls recorded");
 }
 
+int mi_engine_last_phase_parts(const mi_engine *e) { return e ? e->engine->lastPhaseParts() : 0; }
+
+int mi_engine_set_kernel_timing_stride(mi_engine *e, int every) {
+  if (!e || every < 1) {
+    return Fail(MI_ERR_ARG, "timing stride must be >= 1");
+  }
+  e->engine->SetTimingStride(every);
+  return MI_OK;
+}
+
 double mi_engine_last_kernel_ms(mi_engine *e) { return e ? e->engine->LastKernelMs() : -1.0; }
 
 int mi_engine_enable_class_timing(mi_engine *e, int on) {

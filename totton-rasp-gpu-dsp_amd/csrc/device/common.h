@@ -281,7 +281,11 @@ struct IoDesc {
   // runs ([workgroup][16 slots][T] + [17] self lanes, 16 bytes each = kSplitParkWords f4 per workgroup); null = the
   // second half recomputes its spectral products (the round-2 form)
   f4 *park;
+  // fused_parts_kernel: workgroups per work item (a divisor of P, >= 2); 0 elsewhere
+  int phase_parts;
 };
+// smallest transform length (log2) that has a fused_parts_kernel
+constexpr int kPartsMinLog2K = 10;
 // f4 words per workgroup of IoDesc::park for a split kernel of T threads
 MI_HD constexpr int split_park_words(int threads) { return 16 * threads + 32; }
 

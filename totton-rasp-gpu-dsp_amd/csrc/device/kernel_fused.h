@@ -1674,9 +1674,9 @@ struct FusedKernel {
   // into this channel's staging planes (scr_c = [P][Bc] floats).
   // EXT: the frames are written by interleave_*_kernel (groups narrower than a frame); the
   // staging planes are then not read back by this kernel and are stored with streaming stores.
-  template <bool EXT>
+  template <bool EXT, bool PARTS = false>
   static MI_DEVICE void channel_block(const Geometry &g, const IoDesc &io, const BlockIo &b, float *scr_c,
-                                      const FusedTables &ft, cf *lds, int tid, int cc) {
+                                      const FusedTables &ft, cf *lds, int tid, int cc, int pLo = 0, int pHi = 0) {
     const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
     (void)sb;
     MI_STAMP(sb + 0);
@@ -1715,7 +1715,9 @@ struct FusedKernel {
     // Workgroups that share an XCD run in near lockstep and would all pull the same
     // spectrum lines out of the same L2 channels at the same moment (measured: 3.5x
     // slower phase-spectrum loads). Each starts its phase loop at a different phase.
-    const int rot = (MI_BID_X >> 3) + cc;
+    // PARTS (fused_parts_kernel): this workgroup computes phases [pLo, pHi) only; its siblings of the same unit take the
+    // others, so the rotation must not depend on the workgroup
+    const int rot = PARTS ? cc : (MI_BID_X >> 3) + cc;
     if constexpr (W == 1) {
       // ---- narrow form: one set per lane, mirror set in lane ^ 32 ----
       const int blk = ft.blockB[tid];  // this lane's LDS block in the two stride-1 passes
@@ -1769,14 +1771,14 @@ struct FusedKernel {
         MI_STAMP(sp + 8);
       }
     } else {
-      channel_block_wide<EXT>(g, b, scr_c, ft, lds, tid, sb, evenOc, rot);
+      channel_block_wide<EXT, PARTS>(g, b, scr_c, ft, lds, tid, sb, evenOc, rot, pLo, pHi);
     }
   }
 
   // the wide form's second half: last forward pass in registers, split, phase loop
-  template <bool EXT>
+  template <bool EXT, bool PARTS = false>
   static MI_DEVICE void channel_block_wide(const Geometry &g, const BlockIo &b, float *scr_c, const FusedTables &ft, cf *lds,
-                                           int tid, int sb, bool evenOc, int rot) {
+                                           int tid, int sb, bool evenOc, int rot, int pLo = 0, int pHi = 0) {
     (void)sb;
     constexpr int kFirstMidStride = R32 ? 0 : ((R0 > 1) ? S0 / 16 : S0 / 256);
     const int blkA = Cfg::block_a(tid);
@@ -1795,7 +1797,8 @@ struct FusedKernel {
     MI_STAMP(sb + 8);
 
     // --------------------------- per output phase ------------------------
-    for (int pi = 0; pi < g.P; ++pi) {
+    const int piLo = PARTS ? pLo : 0, piHi = PARTS ? pHi : g.P;
+    for (int pi = piLo; pi < piHi; ++pi) {
       const int p = (pi + rot) % g.P;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 16 * T;
       const f4 *g0 = ft.G0 + p * 17;
@@ -2025,7 +2028,10 @@ struct FusedKernel {
   }
 
   // work item = (block, stream, channel group); it = (blk*streams + s)*groups + grp
-  template <bool SPLIT, bool EXT>
+  // PARTS: io.phase_parts consecutive workgroups share one work item and take P / phase_parts phases of it each (each
+  // repeats the forward transform): a call too small to fill the chip finishes in about 1/phase_parts of the phase loop.
+  // Wide form, external epilogue only.
+  template <bool SPLIT, bool EXT, bool PARTS = false>
   static MI_DEVICE void run(const Geometry &g, const IoDesc &io, const FusedTables &ft, cf *lds) {
     const int tid = MI_TID_X;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
@@ -2041,15 +2047,21 @@ struct FusedKernel {
 #else
     const int local = xk * xq + (xk < xr ? xk : xr) + hw / 8;
 #endif
+    int unit = local, pLo = 0, pHi = 0;
+    if constexpr (PARTS) {
+      unit = local / io.phase_parts;
+      pLo = (local - unit * io.phase_parts) * (g.P / io.phase_parts);
+      pHi = pLo + g.P / io.phase_parts;
+    }
     // item = (stream*groups + group) * blocks + block   (block fastest)
-    const int item = io.item0 + local;
+    const int item = io.item0 + unit;
     // item = (stream*blocks + block)*groups + group   (group fastest: a chunk of items
     // holds whole frames, which the external epilogue needs)
     const int sb = item / io.groups;
     const int c0 = (item - sb * io.groups) * io.cg;
     const int s = sb / io.blocks;
     const int blk = sb - s * io.blocks;
-    float *scr = io.scratch + static_cast<long long>(local) * io.cg * g.P * g.Bp;
+    float *scr = io.scratch + static_cast<long long>(unit) * io.cg * g.P * g.Bp;
     for (int cc = 0; cc < io.cg; ++cc) {
       const BlockIo b = make_block_io(g, io, s, c0 + cc, blk);
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
@@ -2058,7 +2070,7 @@ struct FusedKernel {
         f4 *park = io.park ? io.park + static_cast<long long>(local) * split_park_words(T) : nullptr;
         channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, park);
       } else {
-        channel_block<EXT>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc);
+        channel_block<EXT, PARTS>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, pLo, pHi);
       }
     }
     MI_STAMP(128);
@@ -2091,6 +2103,15 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, W>::T < 64 ? 64 : FusedCfg<LOG2K, W>
     Geometry g, IoDesc io, FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
   FusedKernel<LOG2K, W, R32>::template run<false, EXT>(g, io, ft, lds);
+}
+
+// Small calls (fewer work items than half the CUs): every work item is shared by io.phase_parts workgroups, each taking
+// P / phase_parts of its output phases (FusedKernel::run<..., PARTS>); the frames come from interleave_*_kernel.
+template <int LOG2K>
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K, 2>::T < 64 ? 64 : FusedCfg<LOG2K, 2>::T), MIUPS_WIDE_WAVES) void fused_parts_kernel(
+    Geometry g, IoDesc io, FusedTables ft) {
+  MI_DYN_SHARED(cf, lds);
+  FusedKernel<LOG2K, 2, false>::template run<false, true, true>(g, io, ft, lds);
 }
 
 // Block transform length 2 * 2^LOG2K (K = 32768 for the 2x filters at N = 131072): see

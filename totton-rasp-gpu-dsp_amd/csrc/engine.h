@@ -139,6 +139,11 @@ class Engine {
   // kernel timing: up to `slots` most recent calls keep a hipEvent pair around
   // their main kernel(s), recorded on the stream the kernels are launched on
   bool EnableTiming(int slots, std::string *error);
+  // every n-th process call carries the event pair (n >= 1): a pair costs ~8 us of stream time at the headline shape
+  // (scripts/step_overhead.py, profiles/r03_n_step_overhead.txt), a timed region may not want it on every call
+  // workgroups per (block, stream, channel) of the latest fused call: 0 = the plain form, >= 2 = phase-split (small calls)
+  int lastPhaseParts() const { return parts_; }
+  void SetTimingStride(int every) { timingEvery_ = every < 1 ? 1 : every; }
   double LastKernelMs();
   // Per kernel class of the LATEST call: [0] planarize, [1] transform, [2] frame assembly (interleave_*), [3] history
   // carry -- each launch bracketed by its own event pair on the stream it runs on (so: a diagnostic, the extra event
@@ -166,6 +171,7 @@ class Engine {
   bool fused_ = false;
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
+  int parts_ = 0;                  // fused path, small calls: workgroups per (block, stream, channel) (phase-split), else 0
   std::size_t wgCapacity_ = 256;   // fused path: workgroups resident on the whole chip at once
   float *scratch_ = nullptr;       // fused path: fp32 staging planes (two halves when launches are pipelined)
   std::size_t scratchBytes_ = 0;
@@ -204,6 +210,8 @@ class Engine {
   // timing
   std::vector<void *> evStart_, evStop_;
   long long evCount_ = 0;
+  long long timingCalls_ = 0;
+  int timingEvery_ = 1;
 };
 
 // Pinned host memory for ProcessHost callers (hipHostMalloc / hipHostFree).

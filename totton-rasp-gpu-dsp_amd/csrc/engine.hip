@@ -889,6 +889,25 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   }
   cg_ = whole ? channels_ : 1;
   groups_ = channels_ / cg_;
+  // A call with far fewer work items than CUs (the reference's own call shape is ONE channel-block) leaves the chip idle
+  // while one workgroup walks through all P phases: give every (block, stream, channel) `parts_` workgroups that take
+  // P / parts_ phases each (each repeats the forward transform) and let the interleave kernel write the frames.
+  // mi_ups_process_block at the headline filter: kernel 60 -> 2x us (profiles/r03_n_step_overhead.txt).
+  parts_ = 0;
+  const std::size_t units = blocks * static_cast<std::size_t>(streams_) * channels_;
+  if (!filter_->fusedSplit() && !narrow && !filter_->fusedR32() && g.log2k >= kPartsMinLog2K && g.log2k <= 14 &&
+      std::getenv("MIUPS_EXP_NO_PHASE_PARTS") == nullptr) {  // experiment switch (profiles/)
+    for (int d = g.P; d >= 2; --d) {
+      if (g.P % d == 0 && units * static_cast<std::size_t>(d) <= static_cast<std::size_t>(cuCount_)) {
+        parts_ = d;
+        break;
+      }
+    }
+  }
+  if (parts_) {
+    cg_ = 1;
+    groups_ = channels_;
+  }
 }
 
 // class timing (diagnostic): begin/end event around one launch on the stream it is enqueued on
@@ -997,7 +1016,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   io.out_fmt = outFmt_;
   io.blocks = static_cast<int>(blocks);
 
-  const bool timing = !evStart_.empty();
+  const bool timing = !evStart_.empty() && (timingCalls_++ % timingEvery_) == 0;
   const std::size_t slot = timing ? static_cast<std::size_t>(evCount_ % static_cast<long long>(evStart_.size())) : 0;
   if (timing) {
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
@@ -1007,7 +1026,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // the fp32 staging planes (channels * B floats per pair) stay bounded.
     PickChannelGroup(blocks);
     const bool split = filter_->fusedSplit();
-    const bool ext = cg_ < channels_ || split;  // the split kernel has no epilogue of its own
+    const bool ext = cg_ < channels_ || split || parts_ > 0;  // the split and phase-split kernels have no epilogue of their own
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
     std::size_t budget = static_cast<std::size_t>(1024) << 20;
@@ -1099,6 +1118,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       ioF.in_stream_stride = ioF.in_plane_stride * channels_;
     }
     ioF.ext_epilogue = ext ? 1 : 0;
+    ioF.phase_parts = parts_;
     ioF.split_planes = split ? 1 : 0;
     ioF.park = nullptr;
     if (split && std::getenv("MIUPS_EXP_PARK") != nullptr) {  // experiment switch (profiles/r03_g_split_park.txt): measured 0.89x
@@ -1132,7 +1152,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       ioF.scratch = planes;
       ClassMark(1, st, true);
       if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), filter_->fusedR32(),
-                         static_cast<unsigned>(np * groups_), st, error)) {
+                         static_cast<unsigned>(np * groups_ * static_cast<std::size_t>(parts_ ? parts_ : 1)), st, error)) {
         return false;
       }
       ClassMark(1, st, false);
@@ -1345,6 +1365,13 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     stageOutBytes_ = outRow * streams_;
   }
   hipStream_t own = static_cast<hipStream_t>(own_), h2d = static_cast<hipStream_t>(h2d_), d2h = static_cast<hipStream_t>(d2h_);
+  // One sub-batch (the reference's own call shape: one block per call) has nothing to overlap: copy in, kernels and copy
+  // out follow each other on the engine's stream, without the three cross-stream events of the pipelined form
+  // (mi_ups_process_block p50 132 -> see profiles/r03_n_step_overhead.txt).
+  const bool oneStream = nsub == 1 && std::getenv("MIUPS_EXP_HOST_THREE_STREAMS") == nullptr;  // experiment switch (profiles/)
+  if (oneStream) {
+    h2d = d2h = own;
+  }
   if (!OrderAfterLast(own_, error)) {
     return false;
   }
@@ -1379,8 +1406,10 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
                               hipMemcpyHostToDevice, h2d));
       }
     }
-    MI_HIP(hipEventRecord(evIn, h2d));
-    MI_HIP(hipStreamWaitEvent(own, evIn, 0));
+    if (!oneStream) {
+      MI_HIP(hipEventRecord(evIn, h2d));
+      MI_HIP(hipStreamWaitEvent(own, evIn, 0));
+    }
     if (j >= 2) {
       MI_HIP(hipStreamWaitEvent(own, evOut, 0));  // the output of j-2 has left this output slot
     }
@@ -1390,10 +1419,16 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
       (void)hipStreamSynchronize(d2h);
       return false;
     }
-    MI_HIP(hipEventRecord(evRun, own));
-    MI_HIP(hipStreamWaitEvent(d2h, evRun, 0));
-    if (packOut) {
-      MI_HIP(hipEventSynchronize(evRun));  // kernels done: the synchronous copies below may read the output slot
+    if (!oneStream) {
+      MI_HIP(hipEventRecord(evRun, own));
+      MI_HIP(hipStreamWaitEvent(d2h, evRun, 0));
+    }
+    if (packOut) {  // kernels done: the synchronous copies below may read the output slot
+      if (oneStream) {
+        MI_HIP(hipStreamSynchronize(own));
+      } else {
+        MI_HIP(hipEventSynchronize(evRun));
+      }
     }
     for (int s = 0; s < streams_; ++s) {
       if (packOut) {
@@ -1415,9 +1450,13 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
                               hipMemcpyDeviceToHost, d2h));
       }
     }
-    MI_HIP(hipEventRecord(evOut, d2h));
+    if (!oneStream) {
+      MI_HIP(hipEventRecord(evOut, d2h));
+    }
   }
-  MI_HIP(hipStreamSynchronize(d2h));
+  if (!oneStream) {
+    MI_HIP(hipStreamSynchronize(d2h));
+  }
   MI_HIP(hipStreamSynchronize(own));
   return true;
 }
@@ -1553,6 +1592,7 @@ bool Engine::EnableTiming(int slots, std::string *error) {
   evStart_.clear();
   evStop_.clear();
   evCount_ = 0;
+  timingCalls_ = 0;
   for (int i = 0; i < slots; ++i) {
     hipEvent_t a, b;
     MI_HIP(hipEventCreate(&a));

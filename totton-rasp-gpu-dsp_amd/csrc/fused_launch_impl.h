@@ -26,6 +26,23 @@ bool LaunchFusedVariant(const Geometry &g, const IoDesc &io, const FusedTables &
   return HipOk(hipGetLastError(), "fused_kernel launch", error);
 }
 
+// small calls: io.phase_parts workgroups per work item (fused_parts_kernel), sizes 2^10 .. 2^14
+template <int LOG2K>
+bool LaunchFusedParts(const Geometry &g, const IoDesc &io, const FusedTables &ft, unsigned items, hipStream_t st,
+                      std::string *error) {
+  using Cfg = FusedCfg<LOG2K, 2>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_parts_kernel<LOG2K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((fused_parts_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES, st, g, io, ft);
+  return HipOk(hipGetLastError(), "fused_parts_kernel launch", error);
+}
+
 // narrow = the tables are in the narrow layout (K >= 1024): one butterfly per thread; r32 = the tables follow the
 // radix-32 pass plan (wide form, K = 8192 / 16384)
 template <int LOG2K>
@@ -42,6 +59,17 @@ bool LaunchFused(const Geometry &g, const IoDesc &io, const FusedTables &ft, boo
   if (narrow) {
     if (error) {
       *error = "narrow tables without a narrow kernel";
+    }
+    return false;
+  }
+  if (io.phase_parts > 1) {  // `items` counts workgroups: work items * phase_parts
+    if constexpr (LOG2K >= kPartsMinLog2K) {
+      if (!r32 && io.ext_epilogue && g.P % io.phase_parts == 0) {
+        return LaunchFusedParts<LOG2K>(g, io, ft, items, st, error);
+      }
+    }
+    if (error) {
+      *error = "phase-split launch asked of a kernel that has no such form";
     }
     return false;
   }
