@@ -381,6 +381,14 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
         roof["traffic"] = int(rec["bytes"])
         roof["traffic_over_algorithmic"] = round(rec["bytes"] / bytes_launch, 3)
         roof["traffic_source"] = rec["source"] + " (separate rocprofv3 --pmc passes; 2*FETCH_SIZE + WRITE_SIZE)"
+        if "issue" in rec:
+            # what bounds the kernel when HBM does not: a lone wave issues one VALU instruction per 4.94 clocks
+            # (profiles/r02_a_ubench_valu_lds_rates.txt), so this share of every wave's lifetime is VALU issue alone
+            iv = dict(rec["issue"])
+            iv["valu_issue_share_of_wave_clocks"] = round(iv["valu_insts_per_wave"] * 4.94 / iv["wave_clocks"], 3)
+            iv["what"] = ("SQ counters of the same kernel, per launch (separate --pmc passes): the transform is VALU-issue / "
+                          "LDS-write bound with its memory phases not overlapped (one workgroup owns the CU), not HBM-bound")
+            roof["issue_view"] = iv
     return {"value": round(samples / elapsed / 1e6, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "roofline": roof}
 
 
