@@ -137,6 +137,10 @@ const char *mi_engine_path(const mi_engine *e);
  * several workgroups (each repeats the forward transform): returns that count for the latest call, 0 = not split.
  * The reference's own call shape, one channel-block per call, takes P workgroups instead of one. */
 int mi_engine_last_phase_parts(const mi_engine *e);
+/* 1 when the latest call of a "staged" engine (transform lengths past the fused kernels: the 640 001-tap "2m" filters at
+ * 2x / 4x / 8x) ran the two-level transforms -- K = K1 x M2 with the M2-point rows in LDS, two HBM round trips per transform
+ *  -- and 0 when it ran one launch per radix-16 pass (K outside 2^15 .. 2^18, or MIUPS_EXP_NO_TWO_LEVEL). */
+int mi_engine_last_two_level(const mi_engine *e);
 
 /* Process `blocks` consecutive blocks of every stream. d_in / d_out are DEVICE
  * pointers: stream s starts at base + s*stride bytes and holds interleaved

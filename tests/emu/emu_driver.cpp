@@ -25,10 +25,12 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "device/kernel_fused.h"
 #include "device/kernels_generic.h"
+#include "device/kernels_tiled.h"
 #include "host/filter_config.h"
 #include "host/spectrum.h"
 
@@ -281,7 +283,12 @@ int main(int argc, char **argv) {
     std::cerr << "split layout not available for this geometry\n";
     return 3;
   }
-  const bool fused = path == "fused" ? true : (path == "staged" ? false : fusedOk);
+  const bool tiled = path == "tiled";  // the two-level path (device/kernels_tiled.h)
+  if (tiled && !tiled_covers(g.log2k)) {
+    std::cerr << "two-level path does not cover this geometry\n";
+    return 3;
+  }
+  const bool fused = path == "fused" ? true : ((path == "staged" || tiled) ? false : fusedOk);
   if (fused && !fusedOk) {
     std::cerr << "fused path does not cover this geometry\n";
     return 3;
@@ -435,6 +442,63 @@ int main(int argc, char **argv) {
             interleave_scalar_kernel(g, ioF, scratch.data(), static_cast<int>(p0), static_cast<int>(np));
           });
         }
+      }
+    } else if (tiled) {
+      // same sequence as Engine::ProcessDevice's two-level branch, in two chunks of pairs (item0 > 0)
+      const int K1 = 1 << tiled_log2k1(g.log2k), M2 = g.K / K1;
+      std::vector<cf> tGs(t.Gs.size()), tGc(t.Gc.size()), tWm(t.Wm.size());
+      for (int k1 = 0; k1 < K1; ++k1) {
+        for (int k2 = 0; k2 < M2; ++k2) {
+          const size_t to = static_cast<size_t>(k1) * M2 + k2, from = static_cast<size_t>(k1) + static_cast<size_t>(K1) * k2;
+          tWm[to] = t.Wm[from];
+          for (int p = 0; p < g.P; ++p) {
+            tGs[static_cast<size_t>(p) * g.K + to] = t.Gs[static_cast<size_t>(p) * g.K + from];
+            tGc[static_cast<size_t>(p) * g.K + to] = t.Gc[static_cast<size_t>(p) * g.K + from];
+          }
+        }
+      }
+      const unsigned pairs = static_cast<unsigned>(blocks) * streams;
+      const unsigned chunk = pairs > 1 ? (pairs + 1) / 2 : pairs;
+      const size_t nmax = static_cast<size_t>(chunk) * channels;
+      std::vector<cf> A(nmax * g.K), X(nmax * g.K), Bw(nmax * g.K * g.P);
+      std::vector<float> planes(nmax * g.P * g.Bp);
+      IoDesc ioT = io;
+      ioT.scratch = planes.data();
+      ioT.cg = 1;
+      ioT.groups = channels;
+      ioT.ext_epilogue = 1;
+      ioT.out_vec_ok = (reinterpret_cast<uintptr_t>(o.data()) % 16 == 0 && outRow % 16 == 0 &&
+                        (static_cast<size_t>(g.B) * channels * 4) % 16 == 0)
+                           ? 1
+                           : 0;
+      auto rows_kernels = [&](auto cfgTag, auto k1Tag, int item0, int n) {
+        constexpr int LOG2M = decltype(cfgTag)::value, KK1 = decltype(k1Tag)::value;
+        using Cfg = TiledRowCfg<LOG2M>;
+        miups_emu::launch(Blocks(static_cast<long long>(n) * M2, 64), 64, 0, false,
+                          [&]() { tiled_load_kernel<KK1>(g, io, t.tw.data(), A.data(), item0, n); });
+        TiledRowSrc plain{A.data(), nullptr, nullptr, nullptr};
+        miups_emu::launch(static_cast<unsigned>(n) * KK1, Cfg::T, Cfg::LDS_BYTES, true,
+                          [&]() { tiled_row_forward_kernel<LOG2M, KK1>(g, plain, t.tw.data(), X.data()); });
+        TiledRowSrc spectral{X.data(), tWm.data(), tGs.data(), tGc.data()};
+        miups_emu::launch(static_cast<unsigned>(n) * g.P * KK1, Cfg::T, Cfg::LDS_BYTES, true,
+                          [&]() { tiled_row_inverse_kernel<LOG2M, KK1>(g, spectral, t.tw.data(), Bw.data()); });
+        const long long rows = static_cast<long long>(n) * g.P;
+        miups_emu::launch(Blocks(rows * M2, 64), 64, 0, false,
+                          [&]() { tiled_store_kernel<KK1>(g, t.tw.data(), Bw.data(), planes.data(), rows); });
+      };
+      for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
+        const unsigned np = std::min(chunk, pairs - p0);
+        const int item0 = static_cast<int>(p0) * channels, n = static_cast<int>(np) * channels;
+        switch (g.log2k) {
+          case 15: rows_kernels(std::integral_constant<int, 11>(), std::integral_constant<int, 16>(), item0, n); break;
+          case 16: rows_kernels(std::integral_constant<int, 12>(), std::integral_constant<int, 16>(), item0, n); break;
+          case 17: rows_kernels(std::integral_constant<int, 13>(), std::integral_constant<int, 16>(), item0, n); break;
+          default: rows_kernels(std::integral_constant<int, 13>(), std::integral_constant<int, 32>(), item0, n); break;
+        }
+        const long long total = static_cast<long long>(np) * g.B * channels;
+        miups_emu::launch(Blocks(total, 64), 64, 0, false, [&]() {
+          interleave_scalar_kernel(g, ioT, planes.data(), static_cast<int>(p0), static_cast<int>(np));
+        });
       }
     } else {
       const size_t row = g.K;

@@ -103,6 +103,51 @@ def test_emulated_pruned_last_pass(emu, O, make_filter, tmp_path, fft, taps, L, 
     test_emulated_kernels_match_truth(emu, O, make_filter, tmp_path, fft, taps, L, path, streams, channels, blocks, calls)
 
 
+TILED_CASES = [  # the two-level path (device/kernels_tiled.h): K = 2^15 .. 2^18 = K1 x M2, M2-point rows in LDS
+    # fft, taps, L, streams, channels, blocks, calls, in_fmt, out_fmt
+    (65536, 20001, 1, 1, 1, 1, 2, "f32", "f32"),    # K = 32768 = 16 x 2048 (rows 8.16.16), history carried to a second call
+    (131072, 40003, 2, 1, 2, 2, 1, "s32", "s32"),   # K = 32768, two phases, stereo PCM, odd history length, chunked pairs
+    (131072, 70001, 1, 2, 1, 1, 1, "f32", "s16"),   # K = 65536 = 16 x 4096 (rows 16.16.16), two streams
+    (262144, 150001, 1, 1, 1, 1, 1, "f32", "f32"),  # K = 131072 = 16 x 8192 (rows 2.16.16.16, 512 threads)
+    (1048576, 640001, 2, 1, 1, 1, 1, "s32", "f32"),  # K = 262144 = 32 x 8192 (radix-32 column passes): the 2x "2m" geometry
+]
+
+
+@pytest.mark.parametrize("fft,taps,L,streams,channels,blocks,calls,in_fmt,out_fmt", TILED_CASES)
+def test_emulated_two_level_path(emu, O, make_filter, tmp_path, fft, taps, L, streams, channels, blocks, calls, in_fmt, out_fmt):
+    """tiled_load / tiled_row_forward / tiled_row_inverse / tiled_store + interleave: against fp64 truth, and against the
+    pass-per-launch staged kernels on the same input (same tables, same arithmetic up to the order of the butterflies)."""
+    rng = np.random.default_rng(fft + taps)
+    h = (rng.standard_normal(taps) * 0.5 / np.sqrt(taps / L)).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    xf = np.clip(rng.standard_normal((calls, streams, blocks * nin, channels)) * 0.1, -1, 1)
+    if in_fmt == "s32":
+        xi = (xf * 2147483647).astype("<i4")
+        x, raw = xi.astype(np.float64) / 2147483648.0, xi.tobytes()
+    else:
+        x32 = xf.astype(np.float32)
+        x, raw = x32.astype(np.float64), x32.tobytes()
+    tiled = run_emu(emu, tmp_path, p, raw, streams, channels, blocks, calls, "tiled", in_fmt, out_fmt)
+    staged = run_emu(emu, tmp_path, p, raw, streams, channels, blocks, calls, "staged", in_fmt, out_fmt)
+    dt = {"f32": np.float32, "s32": "<i4", "s16": "<i2"}[out_fmt]
+    scale = {"f32": 1.0, "s32": 2147483648.0, "s16": 32768.0}[out_fmt]
+    y = np.frombuffer(tiled, dt).reshape(calls, streams, blocks * block, channels).astype(np.float64) / scale
+    ys = np.frombuffer(staged, dt).reshape(calls, streams, blocks * block, channels).astype(np.float64) / scale
+    lsb = 0.0 if out_fmt == "f32" else 1.0 / scale
+    for s_ in range(streams):
+        for c in range(channels):
+            xs = np.concatenate([x[k, s_, :, c] for k in range(calls)])
+            truth = np.clip(O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1), -1.0, float(np.float32(0.9999999))
+                            ) if out_fmt != "f32" else O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1)
+            got = np.concatenate([y[k, s_, :, c] for k in range(calls)])
+            ref = np.concatenate([ys[k, s_, :, c] for k in range(calls)])
+            tol = lsb + 1e-5 * np.abs(truth).max()
+            assert np.abs(got - truth).max() <= tol
+            assert np.abs(got - ref).max() <= 2 * tol
+
+
 PARTS_CASES = [  # the engine's small-call form: EMU_PARTS workgroups per (block, stream, channel), P / parts phases each
     # fft, taps, L, parts, streams, channels, blocks, calls      (K = fft / 2L >= 1024: fused_parts_kernel exists)
     (8192, 2049, 4, 4, 1, 1, 1, 2),    # K = 1024, mono, one phase per workgroup (the reference's call shape)

@@ -532,3 +532,57 @@ def test_640k_tap_filters_select_and_match_truth(ups, O, gpu, tmp_path, ratio, p
     for c in range(2):
         truth = O.truth_stream(x[:, c], h32, L, blocks, block).reshape(-1)
         assert rel_err(y[:, c], truth) <= TOL_TRUTH
+
+
+@pytest.mark.parametrize("ratio,channels,blocks,in_fmt,out_fmt", [
+    (8, 2, 2, "f32", "f32"),   # K = 65536 = 16 x 4096
+    (4, 3, 1, "s32", "s32"),   # K = 131072 = 16 x 8192, odd channel count (scalar frame assembly)
+    (2, 8, 2, "s32", "s16"),   # K = 262144 = 32 x 8192 (radix-32 column passes), 8 channels (tiled frame assembly)
+])
+def test_640k_tap_filters_take_the_two_level_path(ups, O, gpu, tmp_path, monkeypatch, ratio, channels, blocks, in_fmt, out_fmt):
+    """K = 2^16 .. 2^18 (the "2m" filters at 8x / 4x / 2x): the staged engine runs the two-level transforms
+    (device/kernels_tiled.h). Against fp64 truth and against the pass-per-launch form (MIUPS_EXP_NO_TWO_LEVEL=1) on the same
+    PCM over two calls (history carried)."""
+    sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
+    import filter_design as fd
+
+    h = fd.design(640_000, ratio, "48k", "linear")
+    path = fd.export(h, tmp_path, fd.base_name("48k", ratio, 640_000, "linear"), ratio)
+    _, taps, fft, block, L = O.read_filter(path)
+    h32 = np.fromfile(str(path).replace(".json", ".bin"), "<f4")
+    filt = ups.Filter(path, device=gpu)
+    fmt = {"f32": ups.PCM_F32, "s32": ups.PCM_S32, "s16": ups.PCM_S16}
+    nin = block // L
+    rng = np.random.default_rng(ratio)
+    xf = np.clip(rng.standard_normal((2, blocks * nin, channels)) * 0.1, -1, 1)
+    if in_fmt == "s32":
+        xi = (xf * 2147483647).astype("<i4")
+        x, calls = xi.astype(np.float64) / 2147483648.0, [xi[0], xi[1]]
+    else:
+        x32 = xf.astype(np.float32)
+        x, calls = x32.astype(np.float64), [x32[0], x32[1]]
+    dt = {"f32": np.float32, "s32": "<i4", "s16": "<i2"}[out_fmt]
+    scale = {"f32": 1.0, "s32": 2147483648.0, "s16": 32768.0}[out_fmt]
+
+    def run(two_level):
+        eng = ups.Engine(filt, 1, channels, fmt[in_fmt], fmt[out_fmt])
+        assert eng.path == "staged"
+        outs = []
+        for k in range(2):
+            outs.append(eng.process_host(calls[k], blocks).view(dt).reshape(blocks * block, channels).astype(np.float64) / scale)
+            assert eng.last_two_level == two_level
+        eng.close()
+        return np.concatenate(outs)
+
+    y = run(True)
+    monkeypatch.setenv("MIUPS_EXP_NO_TWO_LEVEL", "1")
+    y_old = run(False)
+    lsb = 0.0 if out_fmt == "f32" else 1.0 / scale
+    for c in (0, channels - 1):
+        xs = np.concatenate([x[0, :, c], x[1, :, c]])
+        truth = O.truth_stream(xs, h32, L, 2 * blocks, block).reshape(-1)
+        if out_fmt != "f32":
+            truth = np.clip(truth, -1.0, float(np.float32(0.9999999)))
+        tol = lsb + 1e-5 * np.abs(truth).max()
+        assert np.abs(y[:, c] - truth).max() <= tol
+        assert np.abs(y[:, c] - y_old[:, c]).max() <= 2 * tol

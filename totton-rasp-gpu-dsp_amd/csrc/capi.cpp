@@ -502,6 +502,8 @@ int mi_engine_kernel_ms_stats(mi_engine *e, double *avg, double *min_ms, double 
   return e->engine->KernelMsStats(avg, min_ms, max_ms, count) ? MI_OK : Fail(MI_ERR_DEVICE, "no timed calls recorded");
 }
 
+int mi_engine_last_two_level(const mi_engine *e) { return (e && e->engine->lastTwoLevel()) ? 1 : 0; }
+
 int mi_engine_last_phase_parts(const mi_engine *e) { return e ? e->engine->lastPhaseParts() : 0; }
 
 int mi_engine_set_kernel_timing_stride(mi_engine *e, int every) {

@@ -35,8 +35,10 @@ struct TableSet {
   cf *Gs = nullptr, *Gc = nullptr, *Wm = nullptr, *tw = nullptr, *WmT = nullptr, *selfW = nullptr;
   int *blockB = nullptr;
   f4 *GT = nullptr, *G0 = nullptr;
+  // two-level path (device/kernels_tiled.h, K = 2^15 .. 2^18): Gs / Gc / Wm in its [k1][k2] bin order; else one element
+  cf *tGs = nullptr, *tGc = nullptr, *tWm = nullptr;
   cf wb{1.0f, 0.0f}, wself{1.0f, 0.0f};
-  std::size_t count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // elements per array (pool reuse needs the same shape)
+  std::size_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // elements per array (pool reuse needs the same shape)
   FusedTables fused() const { return FusedTables{tw, WmT, blockB, GT, G0, wb, selfW, wself}; }
   ~TableSet();
 };
@@ -143,6 +145,8 @@ class Engine {
   // (scripts/step_overhead.py, profiles/r03_n_step_overhead.txt), a timed region may not want it on every call
   // workgroups per (block, stream, channel) of the latest fused call: 0 = the plain form, >= 2 = phase-split (small calls)
   int lastPhaseParts() const { return parts_; }
+  // the latest staged call ran the two-level transforms (device/kernels_tiled.h) rather than one launch per pass
+  bool lastTwoLevel() const { return lastTwoLevel_; }
   void SetTimingStride(int every) { timingEvery_ = every < 1 ? 1 : every; }
   double LastKernelMs();
   // Per kernel class of the LATEST call: [0] planarize, [1] transform, [2] frame assembly (interleave_*), [3] history
@@ -160,6 +164,8 @@ class Engine {
   Engine() = default;
   bool EnsureWork(std::size_t items, std::string *error);
   void PickChannelGroup(std::size_t blocks);
+  bool LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
+                    bool quad, void *stream, std::string *error);
   bool EnsureStreams(std::string *error);
   void *TakeEvent();                       // hipEvent_t from the pool
   void Reap(bool all);                     // release table snapshots of finished calls
@@ -171,6 +177,7 @@ class Engine {
   bool fused_ = false;
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
+  bool lastTwoLevel_ = false;
   int parts_ = 0;                  // fused path, small calls: workgroups per (block, stream, channel) (phase-split), else 0
   std::size_t wgCapacity_ = 256;   // fused path: workgroups resident on the whole chip at once
   float *scratch_ = nullptr;       // fused path: fp32 staging planes (two halves when launches are pipelined)

@@ -12,6 +12,7 @@
 #include <sstream>
 
 #include "device/kernels_generic.h"
+#include "device/kernels_tiled.h"
 #include "fused_launch.h"
 #include "hip_check.h"
 #include "host/eq.h"
@@ -127,6 +128,53 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
     pass(4);
   }
   return src;
+}
+
+// The two-level path (device/kernels_tiled.h) for `n` work items starting at item0 (pair-major: whole pairs):
+// PCM -> A (work0) -> X (work1) -> per phase B (work2) -> staging planes.
+template <int LOG2M, int K1>
+bool LaunchTiledSized(const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes,
+                      int item0, int n, hipStream_t st, std::string *error) {
+  using Cfg = TiledRowCfg<LOG2M>;
+  static_assert(Cfg::M * K1 <= (1 << 18), "two-level sizes");
+  static bool attr_set[64] = {};
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  if (Cfg::LDS_BYTES > 64 * 1024 && dev < 64 && !attr_set[dev]) {
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tiled_row_forward_kernel<LOG2M, K1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tiled_row_inverse_kernel<LOG2M, K1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  const int M2 = Cfg::M;
+  const int threads = 256;
+  hipLaunchKernelGGL((tiled_load_kernel<K1>), dim3(Blocks(static_cast<long long>(n) * M2, threads)), dim3(threads), 0, st, g, io,
+                     tabs.tw, A, item0, n);
+  TiledRowSrc plain{A, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL((tiled_row_forward_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * K1), dim3(Cfg::T), Cfg::LDS_BYTES, st,
+                     g, plain, tabs.tw, X);
+  TiledRowSrc spectral{X, tabs.tWm, tabs.tGs, tabs.tGc};
+  hipLaunchKernelGGL((tiled_row_inverse_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * g.P * K1), dim3(Cfg::T),
+                     Cfg::LDS_BYTES, st, g, spectral, tabs.tw, B);
+  const long long rows = static_cast<long long>(n) * g.P;
+  hipLaunchKernelGGL((tiled_store_kernel<K1>), dim3(Blocks(rows * M2, threads)), dim3(threads), 0, st, g, tabs.tw, B, planes, rows);
+  return HipOk(hipGetLastError(), "two-level transform kernels", error);
+}
+
+bool LaunchTiled(const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes, int item0,
+                 int n, hipStream_t st, std::string *error) {
+  switch (g.log2k) {
+    case 15: return LaunchTiledSized<11, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 16: return LaunchTiledSized<12, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 17: return LaunchTiledSized<13, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 18: return LaunchTiledSized<13, 32>(g, io, tabs, A, X, B, planes, item0, n, st, error);
+    default: break;
+  }
+  if (error) {
+    *error = "the two-level path does not cover this transform length";
+  }
+  return false;
 }
 
 // interleave_tiled_kernel<FMT, TI, EPT>: TI in {64, 32, 16}, EPT = rows * TI / 1024 in 1..8
@@ -291,6 +339,9 @@ TableSet::~TableSet() {
   (void)hipFree(blockB);
   (void)hipFree(GT);
   (void)hipFree(G0);
+  (void)hipFree(tGs);
+  (void)hipFree(tGc);
+  (void)hipFree(tWm);
 }
 
 struct TablePool {
@@ -407,14 +458,32 @@ bool DeviceFilter::StageTables(const std::vector<std::complex<double>> *eqHalf, 
     uploadStream_ = st;
   }
   hipStream_t up = static_cast<hipStream_t>(uploadStream_);
-  const std::size_t want[9] = {t.Gs.size(), t.Gc.size(), t.Wm.size(), t.tw.size(), t.WmT.size(),
-                               t.selfW.size(), t.blockB.size(), t.GT.size(), t.G0.size()};
+  // the two-level path's copies of the per-bin tables: bin k = k1 + K1 k2 at [k1][k2]
+  std::vector<cf> tGs, tGc, tWm;
+  if (tiled_covers(t.geo.log2k) && t.Gs.size() == static_cast<std::size_t>(t.geo.P) * t.geo.K) {
+    const int K = t.geo.K, K1 = 1 << tiled_log2k1(t.geo.log2k), M2 = K / K1;
+    tGs.resize(t.Gs.size());
+    tGc.resize(t.Gc.size());
+    tWm.resize(t.Wm.size());
+    for (int k1 = 0; k1 < K1; ++k1) {
+      for (int k2 = 0; k2 < M2; ++k2) {
+        const std::size_t to = static_cast<std::size_t>(k1) * M2 + k2, from = static_cast<std::size_t>(k1) + static_cast<std::size_t>(K1) * k2;
+        tWm[to] = t.Wm[from];
+        for (int p = 0; p < t.geo.P; ++p) {
+          tGs[static_cast<std::size_t>(p) * K + to] = t.Gs[static_cast<std::size_t>(p) * K + from];
+          tGc[static_cast<std::size_t>(p) * K + to] = t.Gc[static_cast<std::size_t>(p) * K + from];
+        }
+      }
+    }
+  }
+  const std::size_t want[12] = {t.Gs.size(), t.Gc.size(), t.Wm.size(), t.tw.size(), t.WmT.size(), t.selfW.size(),
+                                t.blockB.size(), t.GT.size(), t.G0.size(), tGs.size(), tGc.size(), tWm.size()};
   std::unique_ptr<TableSet> set;
   {
     std::lock_guard<std::mutex> lock(pool_->mu);
     for (std::size_t i = 0; i < pool_->free.size(); ++i) {
       bool same = true;
-      for (int k = 0; k < 9; ++k) {
+      for (int k = 0; k < 12; ++k) {
         same = same && pool_->free[i]->count[k] == std::max<std::size_t>(want[k], 1);
       }
       if (same) {
@@ -433,7 +502,9 @@ bool DeviceFilter::StageTables(const std::vector<std::complex<double>> *eqHalf, 
             FillArray(&set->WmT, &set->count[4], t.WmT, up, error) &&
             FillArray(&set->selfW, &set->count[5], t.selfW, up, error) &&
             FillArray(&set->blockB, &set->count[6], t.blockB, up, error) &&
-            FillArray(&set->GT, &set->count[7], t.GT, up, error) && FillArray(&set->G0, &set->count[8], t.G0, up, error);
+            FillArray(&set->GT, &set->count[7], t.GT, up, error) && FillArray(&set->G0, &set->count[8], t.G0, up, error) &&
+            FillArray(&set->tGs, &set->count[9], tGs, up, error) && FillArray(&set->tGc, &set->count[10], tGc, up, error) &&
+            FillArray(&set->tWm, &set->count[11], tWm, up, error);
   if (ok && failNextUpload_) {
     failNextUpload_ = false;
     ok = false;
@@ -910,6 +981,67 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   }
 }
 
+// staging planes of pairs [p0, p0 + np) -> interleaved PCM frames (shared by the fused and the two-level paths)
+bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
+                          bool quad, void *stream, std::string *error) {
+  hipStream_t ist = static_cast<hipStream_t>(stream);
+  const int rows = g.P * channels_;
+  int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
+  if (quad && !split && rows >= 16 && std::getenv("MIUPS_EXP_NO_TILED_INTERLEAVE") == nullptr) {  // experiment switch
+    tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
+    if (const char *ti = std::getenv("MIUPS_EXP_TILE_TI")) {  // experiment switch (profiles/): tile width 16 / 32 / 64
+      tiledTi = std::atoi(ti);
+    }
+    const int per = 1024 / tiledTi;  // rows per 16-byte word of a 256-thread pass over the tile
+    if (rows % per != 0 || rows / per > 8 || rows > 512) {
+      tiledTi = 0;
+    }
+  }
+  if (tiledTi) {
+    const int tiles = (g.Bc + tiledTi - 1) / tiledTi;
+    if (!LaunchInterleaveTiled(g, ioF, planes, static_cast<int>(p0), static_cast<int>(np), tiles, tiledTi,
+                               rows * tiledTi / 1024, outFmt_ == kF32, ist)) {
+      if (error) {
+        *error = "interleave_tiled_kernel: no instantiation for this frame shape";
+      }
+      return false;
+    }
+  } else if (quad && (rows == 4 || rows == 8) && std::getenv("MIUPS_EXP_NO_ROWS_INTERLEAVE") == nullptr) {  // experiment switch
+    const int threads = 256, perWg = threads * (32 / rows);  // interleave_rows_kernel: kDepth = 32 / R
+    const int wgsPerPair = (g.Bc + perWg - 1) / perWg;
+    const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
+    const int sb0 = static_cast<int>(p0), nbp = static_cast<int>(np);
+    if (outFmt_ == kF32) {
+      if (rows == 4) {
+        hipLaunchKernelGGL((interleave_rows_kernel<kF32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+      } else {
+        hipLaunchKernelGGL((interleave_rows_kernel<kF32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+      }
+    } else if (rows == 4) {
+      hipLaunchKernelGGL((interleave_rows_kernel<kS32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+    } else {
+      hipLaunchKernelGGL((interleave_rows_kernel<kS32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
+    }
+  } else if (quad) {
+    const int threads = 256, perWg = threads * 4;  // interleave_quad_kernel: kUnits = 4
+    const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels_ / 4);
+    const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
+    const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
+    if (outFmt_ == kF32) {
+      hipLaunchKernelGGL(interleave_quad_kernel<kF32>, grid, dim3(threads), 0, ist, g, ioF, planes,
+                         static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+    } else {
+      hipLaunchKernelGGL(interleave_quad_kernel<kS32>, grid, dim3(threads), 0, ist, g, ioF, planes,
+                         static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
+    }
+  } else {
+    const long long total = static_cast<long long>(np) * g.B * channels_;
+    hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, ist, g, ioF, planes,
+                       static_cast<int>(p0), static_cast<int>(np));
+  }
+  return true;
+}
+
 // class timing (diagnostic): begin/end event around one launch on the stream it is enqueued on
 bool Engine::ClassMark(int cls, void *stream, bool begin) {
   if (!classTiming_) {
@@ -1021,6 +1153,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   if (timing) {
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
   }
+  lastTwoLevel_ = false;
   if (fused_) {
     // one workgroup per (stream, block, channel group); launches are chunked by whole (stream, block) pairs so that
     // the fp32 staging planes (channels * B floats per pair) stay bounded.
@@ -1167,59 +1300,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       // staging planes of this chunk -> interleaved PCM frames
       ClassMark(2, ist, true);
-      const int rows = g.P * channels_;
-      int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
-      if (quad && !split && rows >= 16 && std::getenv("MIUPS_EXP_NO_TILED_INTERLEAVE") == nullptr) {  // experiment switch
-        tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
-        if (const char *ti = std::getenv("MIUPS_EXP_TILE_TI")) {  // experiment switch (profiles/): tile width 16 / 32 / 64
-          tiledTi = std::atoi(ti);
-        }
-        const int per = 1024 / tiledTi;  // rows per 16-byte word of a 256-thread pass over the tile
-        if (rows % per != 0 || rows / per > 8 || rows > 512) {
-          tiledTi = 0;
-        }
-      }
-      if (tiledTi) {
-        const int tiles = (g.Bc + tiledTi - 1) / tiledTi;
-        if (!LaunchInterleaveTiled(g, ioF, planes, static_cast<int>(p0), static_cast<int>(np), tiles, tiledTi,
-                                   rows * tiledTi / 1024, outFmt_ == kF32, ist)) {
-          if (error) {
-            *error = "interleave_tiled_kernel: no instantiation for this frame shape";
-          }
-          return false;
-        }
-      } else if (quad && (rows == 4 || rows == 8) && std::getenv("MIUPS_EXP_NO_ROWS_INTERLEAVE") == nullptr) {  // experiment switch
-        const int threads = 256, perWg = threads * (32 / rows);  // interleave_rows_kernel: kDepth = 32 / R
-        const int wgsPerPair = (g.Bc + perWg - 1) / perWg;
-        const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
-        const int sb0 = static_cast<int>(p0), nbp = static_cast<int>(np);
-        if (outFmt_ == kF32) {
-          if (rows == 4) {
-            hipLaunchKernelGGL((interleave_rows_kernel<kF32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
-          } else {
-            hipLaunchKernelGGL((interleave_rows_kernel<kF32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
-          }
-        } else if (rows == 4) {
-          hipLaunchKernelGGL((interleave_rows_kernel<kS32, 4>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
-        } else {
-          hipLaunchKernelGGL((interleave_rows_kernel<kS32, 8>), grid, dim3(threads), 0, ist, g, ioF, planes, sb0, nbp, wgsPerPair);
-        }
-      } else if (quad) {
-        const int threads = 256, perWg = threads * 4;  // interleave_quad_kernel: kUnits = 4
-        const long long units = static_cast<long long>(g.Bc / 4) * (g.P * channels_ / 4);
-        const int wgsPerPair = static_cast<int>((units + perWg - 1) / perWg);
-        const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
-        if (outFmt_ == kF32) {
-          hipLaunchKernelGGL(interleave_quad_kernel<kF32>, grid, dim3(threads), 0, ist, g, ioF, planes,
-                             static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
-        } else {
-          hipLaunchKernelGGL(interleave_quad_kernel<kS32>, grid, dim3(threads), 0, ist, g, ioF, planes,
-                             static_cast<int>(p0), static_cast<int>(np), wgsPerPair);
-        }
-      } else {
-        const long long total = static_cast<long long>(np) * g.B * channels_;
-        hipLaunchKernelGGL(interleave_scalar_kernel, dim3(Blocks(total, 256)), dim3(256), 0, ist, g, ioF, planes,
-                           static_cast<int>(p0), static_cast<int>(np));
+      if (!LaunchFrames(g, ioF, planes, p0, np, split, quad, ist, error)) {
+        return false;
       }
       ClassMark(2, ist, false);
       if (!HipOk(hipGetLastError(), "interleave kernel", error)) {
@@ -1235,6 +1317,59 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         if (usedHalf[half]) {
           MI_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(pipeEv_[2 + half]), 0));
         }
+      }
+    }
+  } else if (tiled_covers(g.log2k) && tabs->count[9] == static_cast<std::size_t>(g.P) * g.K &&
+             static_cast<long long>(blocks) * streams_ * channels_ * g.P * 32 < (1ll << 31) &&
+             std::getenv("MIUPS_EXP_NO_TWO_LEVEL") == nullptr) {  // experiment switch (profiles/): the pass-per-launch form
+    // K = 2^15 .. 2^18 outside the fused kernels (the "2m" filters at 2x / 4x / 8x): two-level transforms with the
+    // M2-point rows in LDS (device/kernels_tiled.h), frames by the fused path's interleave kernels
+    cg_ = 1;
+    groups_ = channels_;
+    parts_ = 0;
+    lastTwoLevel_ = true;
+    const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
+    const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
+    const std::size_t perItem = static_cast<std::size_t>(2 + 2 * g.P) * g.K * sizeof(cf);          // EnsureWork's rows
+    const std::size_t budget = static_cast<std::size_t>(1024) << 20;
+    const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / (perItem * channels_ + perPair)));
+    if (!EnsureWork(chunk * channels_, error)) {
+      return false;
+    }
+    if (chunk * perPair > scratchBytes_) {
+      Reap(true);
+      (void)hipFree(scratch_);
+      scratch_ = nullptr;
+      scratchBytes_ = 0;
+      MI_HIP(hipMalloc(reinterpret_cast<void **>(&scratch_), chunk * perPair));
+      scratchBytes_ = chunk * perPair;
+    }
+    IoDesc ioT = io;
+    ioT.scratch = scratch_;
+    ioT.cg = 1;
+    ioT.groups = channels_;
+    ioT.ext_epilogue = 1;
+    ioT.split_planes = 0;
+    ioT.out_vec_ok = (reinterpret_cast<std::uintptr_t>(dOut) % 16 == 0 && outStride % 16 == 0 &&
+                      (static_cast<std::size_t>(g.B) * channels_ * 4) % 16 == 0)
+                         ? 1
+                         : 0;
+    const bool quad = ioT.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 && g.Bc % 4 == 0;
+    for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {
+      const std::size_t np = std::min<std::size_t>(chunk, pairs - p0);
+      ClassMark(1, st, true);
+      if (!LaunchTiled(g, io, *tabs, work_[0], work_[1], work_[2], scratch_, static_cast<int>(p0 * channels_),
+                       static_cast<int>(np * channels_), st, error)) {
+        return false;
+      }
+      ClassMark(1, st, false);
+      ClassMark(2, st, true);
+      if (!LaunchFrames(g, ioT, scratch_, p0, np, false, quad, st, error)) {
+        return false;
+      }
+      ClassMark(2, st, false);
+      if (!HipOk(hipGetLastError(), "interleave kernel", error)) {
+        return false;
       }
     }
   } else {
