@@ -99,19 +99,36 @@ struct TiledRow {
   using Cfg = TiledRowCfg<LOG2M>;
   static constexpr int M = Cfg::M, T = Cfg::T, R0 = Cfg::R0;
 
-  // element i of this workgroup's row
-  static MI_DEVICE cf fetch(const Geometry &g, const TiledRowSrc &src, long long it, int p, int k1, int i) {
-    if constexpr (!SPECTRAL) {
-      (void)g;
-      (void)p;
-      return src.rows[(it * K1 + k1) * M + i];
-    } else {
-      const cf *X = src.rows + it * K1 * M;
+  // this workgroup's rows, as workgroup-uniform pointers (scalar registers): the per-element address is then one 32-bit
+  // offset (the indexed form, (it * K1 + k1) * M + i in 64 bits per element, was ~40 % of the kernel's VALU instructions)
+  struct Rows {
+    const cf *x;    // plain: the row of A; spectral: the row of X
+    const cf *xm;   // spectral: the mirror row of X (read backwards)
+    const cf *w;    // spectral: untangle twiddles of the row
+    const cf *gs;   // spectral: the phase's spectrum words of the row
+    const cf *gc;
+    int k1;
+  };
+  static MI_DEVICE Rows make_rows(const Geometry &g, const TiledRowSrc &src, long long it, int p, int k1) {
+    Rows r{};
+    r.k1 = k1;
+    r.x = src.rows + (it * K1 + k1) * M;
+    if constexpr (SPECTRAL) {
       const int m1 = (K1 - k1) & (K1 - 1);
-      const int m2 = k1 ? M - 1 - i : ((M - i) & (M - 1));
-      const long long tix = static_cast<long long>(k1) * M + i;
-      const long long pix = static_cast<long long>(p) * g.K + tix;
-      return spectral_bin(X[tix], X[static_cast<long long>(m1) * M + m2], src.WmT[tix], src.GsT[pix], src.GcT[pix]);
+      r.xm = src.rows + (it * K1 + m1) * M;
+      r.w = src.WmT + static_cast<long long>(k1) * M;
+      r.gs = src.GsT + static_cast<long long>(p) * g.K + static_cast<long long>(k1) * M;
+      r.gc = src.GcT + static_cast<long long>(p) * g.K + static_cast<long long>(k1) * M;
+    }
+    return r;
+  }
+  // element i of this workgroup's row
+  static MI_DEVICE cf fetch(const Rows &r, int i) {
+    if constexpr (!SPECTRAL) {
+      return r.x[i];
+    } else {
+      const int m2 = r.k1 ? M - 1 - i : ((M - i) & (M - 1));
+      return spectral_bin(r.x[i], r.xm[m2], r.w[i], r.gs[i], r.gc[i]);
     }
   }
 
@@ -120,8 +137,7 @@ struct TiledRow {
   // FROM_GLOBAL: inputs through fetch(); TO_GLOBAL: outputs to dst (lane-contiguous: the last pass has Ns = M/16 >= T);
   // otherwise the LDS buffer, in place: every thread has read before any thread writes (the barrier in the middle).
   template <int R, int NS, bool FROM_GLOBAL, bool TO_GLOBAL>
-  static MI_DEVICE void pass(const Geometry &g, const TiledRowSrc &src, long long it, int p, int k1, const cf *MI_RESTRICT tw,
-                             cf *MI_RESTRICT lds, cf *MI_RESTRICT dst, int tid) {
+  static MI_DEVICE void pass(const Rows &rows, const cf *MI_RESTRICT tw, cf *MI_RESTRICT lds, cf *MI_RESTRICT dst, int tid) {
     constexpr int PER = 16 / R;  // butterflies per thread
     constexpr int LOG2NSR = __builtin_ctz(NS * R);
     static_assert(FROM_GLOBAL || PER == 1, "LDS to LDS passes are radix 16");
@@ -133,7 +149,7 @@ struct TiledRow {
       for (int t = 0; t < R; ++t) {
         const int i = j + t * (M / R);
         if constexpr (FROM_GLOBAL) {
-          v[b][t] = fetch(g, src, it, p, k1, i);
+          v[b][t] = fetch(rows, i);
         } else {
           v[b][t] = lds[tiled_pad(i)];
         }
@@ -172,26 +188,27 @@ struct TiledRow {
     const int p = SPECTRAL ? static_cast<int>(ip % g.P) : 0;
     const long long it = SPECTRAL ? ip / g.P : ip;
     cf *dst = out_rows + (ip * K1 + k1) * M;  // plain: X[item][k1]; spectral: B[item][p][k1]
+    const Rows rows = make_rows(g, src, it, p, k1);
     if constexpr (R0 > 1) {
-      pass<R0, 1, true, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+      pass<R0, 1, true, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
-      pass<16, R0, false, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+      pass<16, R0, false, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
       if constexpr (Cfg::NPASS == 4) {
-        pass<16, R0 * 16, false, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+        pass<16, R0 * 16, false, false>(rows, tw, lds, nullptr, tid);
         MI_SYNC();
       }
-      pass<16, M / 16, false, true>(g, src, it, p, k1, tw, lds, dst, tid);
+      pass<16, M / 16, false, true>(rows, tw, lds, dst, tid);
     } else {
-      pass<16, 1, true, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+      pass<16, 1, true, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
       if constexpr (Cfg::NPASS == 4) {  // M = 65536 would be; kept for symmetry
-        pass<16, 16, false, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+        pass<16, 16, false, false>(rows, tw, lds, nullptr, tid);
         MI_SYNC();
       }
-      pass<16, M / 256, false, false>(g, src, it, p, k1, tw, lds, nullptr, tid);
+      pass<16, M / 256, false, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
-      pass<16, M / 16, false, true>(g, src, it, p, k1, tw, lds, dst, tid);
+      pass<16, M / 16, false, true>(rows, tw, lds, dst, tid);
     }
   }
 };
