@@ -226,15 +226,22 @@ def cpu_baseline(filter_path: Path, budget_s: float) -> dict:
 class Workload:
     """One config resident on this rank's GPU: filter (+EQ), engine, synthetic PCM in HBM."""
 
-    def __init__(self, ups, hip, device, config_id, rank, streams=None, blocks=None, eq=None, channel_slice=None):
+    def __init__(self, ups, hip, device, config_id, rank, streams=None, blocks=None, eq=None, channel_slice=None, custom=None):
         """channel_slice = (first, count): this GPU takes that contiguous channel group of every stream (--split channels);
-        the synthetic frames are the full-width ones, cut -- every channel sees the samples it sees on one GPU."""
-        fname, s, channels, b, desc = CONFIGS[config_id]
+        the synthetic frames are the full-width ones, cut -- every channel sees the samples it sees on one GPU.
+        custom = (filter json path, streams, channels, blocks, description): a workload outside CONFIGS (config_id then only
+        seeds the PCM)."""
+        if custom:
+            fpath, s, channels, b, desc = custom
+            fname = Path(fpath).name
+        else:
+            fname, s, channels, b, desc = CONFIGS[config_id]
+            fpath = ROOT / "data" / "coefficients" / fname
         self.config_id, self.desc, self.fname = config_id, desc, fname
         c0, nch = channel_slice or (0, channels)
         self.full_channels = channels
         self.streams, self.channels, self.blocks = streams or s, nch, blocks or b
-        self.fpath = ROOT / "data" / "coefficients" / fname
+        self.fpath = Path(fpath)
         ok, msg, cfg = ups.read_filter(self.fpath)
         if not ok:
             raise RuntimeError(msg)
@@ -375,7 +382,7 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
             "kernel_ms_min": round(kstat["min"], 5), "kernel_launches_timed": kstat["count"],
             "timed_every_nth_launch": getattr(w, "timing_every", 1),
             "algorithmic_bytes_per_launch": int(bytes_launch)}
-    key = str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks"
+    key = (str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks") if w.config_id in CONFIGS else ""
     rec = (traffic or {}).get(key)
     if rec and (rec["streams"], rec["channels"], rec["blocks"]) == (w.streams, w.channels, w.blocks):
         roof["traffic"] = int(rec["bytes"])
@@ -393,7 +400,8 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
 
 
 def config_block(w: Workload) -> dict:
-    return {"workload": f"configs[{w.config_id - 1}]: {w.desc}", "filter": w.fname, "taps": w.cfg["taps"],
+    name = f"configs[{w.config_id - 1}]: {w.desc}" if w.config_id in CONFIGS else w.desc
+    return {"workload": name, "filter": w.fname, "taps": w.cfg["taps"],
             "fft_size": w.cfg["fft_size"], "block_size": w.cfg["block_size"], "upsample_factor": w.cfg["upsample_factor"],
             "streams_per_gpu": w.streams, "channels": w.channels, "blocks_per_channel": w.blocks,
             "pcm": "s32 interleaved in/out", "eq": bool(w.use_eq), "kernel_path": w.eng.path}
@@ -473,6 +481,30 @@ def process_block_latency(ups, device, filter_path, calls=1000) -> dict:
             "mean_ms": round(float(ms.mean()), 4), "Msamples_per_s_at_p50": round(cfg["block_size"] / ms[calls // 2] / 1e3, 2),
             "block_audio_ms_at_output_rate": round(cfg["block_size"] / (44100.0 * cfg["upsample_factor"]) * 1e3, 2),
             "what": "mi_ups_process_block, one channel-block per call (host float in/out, blocking), headline filter"}
+
+
+def filters_2m(ups, hip, device, args, ceiling) -> list:
+    import tempfile
+
+    sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
+    import filter_design as fd
+
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for cid, ratio in ((6, 8), (7, 2)):
+            h = fd.design(640_000, ratio, "48k", "linear")
+            path = fd.export(h, Path(tmp), fd.base_name("48k", ratio, 640_000, "linear"), ratio)
+            wl = Workload(ups, hip, device, cid, 0, custom=(path, 1, 8, 16, f"48k {ratio}x linear 640k-tap ('2m'), 8ch"))
+            if args.prime_seconds > 0:
+                wl.prime(args.prime_seconds)
+            _, el, ks = wl.run(max(5, args.steps // 4), 2)
+            sm = summary(wl, max(5, args.steps // 4), el, ks, 1, None)
+            sm["roofline"]["frac_of_copy_ceiling"] = round(sm["roofline"]["achieved"] / ceiling, 5)
+            rows.append({"config": config_block(wl), "value": sm["value"], "unit": "Msamples/s", "ms_per_step": sm["ms_per_step"],
+                         "roofline": sm["roofline"], "two_level": bool(wl.eng.last_two_level), "output_check": wl.check_output(),
+                         "per_kernel_ms": wl.per_kernel_ms()})
+            wl.close()
+    return rows
 
 
 def copy_ceiling(ups, device) -> dict:
@@ -807,6 +839,9 @@ def run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, 
             if wc is not w:
                 wc.close()
         extras["configs"] = rows
+        # the 640 001-tap "2m" filters the selector prefers when present (alsa_filter_selector.cpp:74-96): transforms of
+        # 2^16 / 2^18 points, past the fused kernels -- the two-level path. Designed here by the repo's generator.
+        extras["filters_2m"] = filters_2m(ups, hip, device, args, head["roofline"]["copy_ceiling_GBps"])
         extras["per_kernel_ms"] = ("roofline.kernel_ms_* = one hipEvent pair around all kernels of a call; configs[].per_kernel_ms = "
                                    "untimed extra steps with one event pair per launch (planarize / transform / frames / history; "
                                    "launches that overlap on two streams add up to more than the call); rocprofv3 --kernel-trace "
