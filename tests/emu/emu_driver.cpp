@@ -471,11 +471,31 @@ int main(int argc, char **argv) {
                         (static_cast<size_t>(g.B) * channels * 4) % 16 == 0)
                            ? 1
                            : 0;
+      // the engine's rule: interleaved frames (two or more channels, S = 1) go through planarize_kernel first
+      IoDesc ioL = io;
+      std::vector<float> planarT;
+      if (channels >= 2 && g.S == 1 && g.hist_frames == g.Oc && !std::getenv("EMU_TILED_NO_PLANAR")) {
+        const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
+        const long long planeFloats = (total + 3) / 4 * 4;
+        planarT.assign(static_cast<size_t>(planeFloats) * channels * streams, 0.0f);
+        const int tileFrames = planar_tile_frames(channels);
+        const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
+        IoDesc ioP = io;
+        ioP.split_planes = 0;
+        miups_emu::launch(static_cast<unsigned>(tiles) * streams, 256,
+                          static_cast<size_t>(channels) * (tileFrames + 1) * sizeof(float), true,
+                          [&]() { planarize_kernel(g, ioP, planarT.data(), planeFloats, total, tiles, tileFrames); });
+        ioL.in = planarT.data();
+        ioL.in_fmt = kF32;
+        ioL.in_planar = 1;
+        ioL.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
+        ioL.in_stream_stride = ioL.in_plane_stride * channels;
+      }
       auto rows_kernels = [&](auto cfgTag, auto k1Tag, int item0, int n) {
         constexpr int LOG2M = decltype(cfgTag)::value, KK1 = decltype(k1Tag)::value;
         using Cfg = TiledRowCfg<LOG2M>;
         miups_emu::launch(Blocks(static_cast<long long>(n) * M2, 64), 64, 0, false,
-                          [&]() { tiled_load_kernel<KK1>(g, io, t.tw.data(), A.data(), item0, n); });
+                          [&]() { tiled_load_kernel<KK1>(g, ioL, t.tw.data(), A.data(), item0, n); });
         TiledRowSrc plain{A.data(), nullptr, nullptr, nullptr};
         miups_emu::launch(static_cast<unsigned>(n) * KK1, Cfg::T, Cfg::LDS_BYTES, true,
                           [&]() { tiled_row_forward_kernel<LOG2M, KK1>(g, plain, t.tw.data(), X.data()); });

@@ -56,10 +56,23 @@ MI_GLOBAL void tiled_load_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT tw
   int s, blk, c;
   tiled_item(io, item0 + it, s, blk, c);
   cf v[K1];
-  MI_UNROLL
-  for (int n1 = 0; n1 < K1; ++n1) {
-    const int n = n1 * M2 + n2;  // complex word of the compact block: samples 2n, 2n + 1
-    v[n1] = mk(compact_sample(g, io, s, c, blk, 2 * n), compact_sample(g, io, s, c, blk, 2 * n + 1));
+  if (io.in_planar == 1) {
+    // one fp32 timeline per channel (planarize_kernel; S = 1 and hist_frames = Oc): compact sample n of block blk is
+    // timeline sample blk * Bc + n -- lanes read consecutive 8-byte words
+    const float *tl = reinterpret_cast<const float *>(static_cast<const char *>(io.in) + s * io.in_stream_stride +
+                                                      c * io.in_plane_stride) +
+                      static_cast<long long>(blk) * g.Bc;
+    MI_UNROLL
+    for (int n1 = 0; n1 < K1; ++n1) {
+      const int n = 2 * (n1 * M2 + n2);
+      v[n1] = mk(tl[n], tl[n + 1]);
+    }
+  } else {
+    MI_UNROLL
+    for (int n1 = 0; n1 < K1; ++n1) {
+      const int n = n1 * M2 + n2;  // complex word of the compact block: samples 2n, 2n + 1
+      v[n1] = mk(compact_sample(g, io, s, c, blk, 2 * n), compact_sample(g, io, s, c, blk, 2 * n + 1));
+    }
   }
   dftR<-1, K1>(v);
   if (n2 > 0) {

@@ -164,6 +164,8 @@ class Engine {
   Engine() = default;
   bool EnsureWork(std::size_t items, std::string *error);
   void PickChannelGroup(std::size_t blocks);
+  bool PlanarizeInput(const Geometry &g, const IoDesc &io, std::size_t blocks, bool splitPlanar, void *stream, IoDesc *ioF,
+                      std::string *error);
   bool LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
                     bool quad, void *stream, std::string *error);
   bool EnsureStreams(std::string *error);

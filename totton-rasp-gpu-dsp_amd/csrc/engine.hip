@@ -981,6 +981,42 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   }
 }
 
+// Wide frames: de-interleave (history ++ new frames) once, coalesced, into one fp32 timeline per channel (planar_) and
+// point `ioF` at it, instead of gathering one sample per cache line in every channel's first pass.
+bool Engine::PlanarizeInput(const Geometry &g, const IoDesc &io, std::size_t blocks, bool splitPlanar, void *stream, IoDesc *ioF,
+                            std::string *error) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
+  const long long planeFloats = (total + 3) / 4 * 4;
+  const std::size_t need = static_cast<std::size_t>(planeFloats) * channels_ * streams_ * sizeof(float);
+  if (need > planarBytes_) {
+    Reap(true);
+    (void)hipFree(planar_);
+    planar_ = nullptr;
+    planarBytes_ = 0;
+    MI_HIP(hipMalloc(reinterpret_cast<void **>(&planar_), need));
+    planarBytes_ = need;
+  }
+  const int tileFrames = planar_tile_frames(channels_);
+  const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
+  const std::size_t lds = static_cast<std::size_t>(channels_) * (tileFrames + 1) * sizeof(float);
+  IoDesc ioP = io;
+  ioP.split_planes = splitPlanar ? 1 : 0;
+  ClassMark(0, st, true);
+  hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP, planar_,
+                     planeFloats, total, tiles, tileFrames);
+  ClassMark(0, st, false);
+  if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
+    return false;
+  }
+  ioF->in = planar_;
+  ioF->in_fmt = kF32;
+  ioF->in_planar = splitPlanar ? 2 : 1;
+  ioF->in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
+  ioF->in_stream_stride = ioF->in_plane_stride * channels_;
+  return true;
+}
+
 // staging planes of pairs [p0, p0 + np) -> interleaved PCM frames (shared by the fused and the two-level paths)
 bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
                           bool quad, void *stream, std::string *error) {
@@ -1219,36 +1255,9 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     const bool splitPlanar = split && g.Bc % 4 == 0 && g.hist_frames == g.Oc && g.Oc % 4 == 0 &&
                              std::getenv("MIUPS_EXP_NO_SPLIT_PLANAR") == nullptr;  // experiment switch (profiles/)
     if ((channels_ > 2 || splitPlanar) && channels_ <= kMaxPlanarChannels) {
-      // wide frames: de-interleave (history ++ new frames) once, coalesced, instead of
-      // gathering one sample per cache line in every channel's first pass
-      const long long total = static_cast<long long>(g.hist_frames) + static_cast<long long>(blocks) * g.n_in;
-      const long long planeFloats = (total + 3) / 4 * 4;
-      const std::size_t need = static_cast<std::size_t>(planeFloats) * channels_ * streams_ * sizeof(float);
-      if (need > planarBytes_) {
-        Reap(true);
-        (void)hipFree(planar_);
-        planar_ = nullptr;
-        planarBytes_ = 0;
-        MI_HIP(hipMalloc(reinterpret_cast<void **>(&planar_), need));
-        planarBytes_ = need;
-      }
-      const int tileFrames = planar_tile_frames(channels_);
-      const int tiles = static_cast<int>((total + tileFrames - 1) / tileFrames);
-      const std::size_t lds = static_cast<std::size_t>(channels_) * (tileFrames + 1) * sizeof(float);
-      IoDesc ioP = io;
-      ioP.split_planes = splitPlanar ? 1 : 0;
-      ClassMark(0, st, true);
-      hipLaunchKernelGGL(planarize_kernel, dim3(static_cast<unsigned>(tiles) * streams_), dim3(256), lds, st, g, ioP,
-                         planar_, planeFloats, total, tiles, tileFrames);
-      ClassMark(0, st, false);
-      if (!HipOk(hipGetLastError(), "planarize_kernel", error)) {
+      if (!PlanarizeInput(g, io, blocks, splitPlanar, st, &ioF, error)) {
         return false;
       }
-      ioF.in = planar_;
-      ioF.in_fmt = kF32;
-      ioF.in_planar = splitPlanar ? 2 : 1;
-      ioF.in_plane_stride = planeFloats * static_cast<long long>(sizeof(float));
-      ioF.in_stream_stride = ioF.in_plane_stride * channels_;
     }
     ioF.ext_epilogue = ext ? 1 : 0;
     ioF.phase_parts = parts_;
@@ -1355,10 +1364,19 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
                          ? 1
                          : 0;
     const bool quad = ioT.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 && g.Bc % 4 == 0;
+    // interleaved frames: the column pass of one channel would use 4 bytes of every frame it touches (2x, 8 channels:
+    // 160 of 500 us per launch, profiles/r03_q_two_level.txt) -- one fp32 timeline per channel first, as for wide fused frames
+    IoDesc ioL = io;
+    if (channels_ >= 2 && channels_ <= kMaxPlanarChannels && g.S == 1 && g.hist_frames == g.Oc &&
+        std::getenv("MIUPS_EXP_TWO_LEVEL_NO_PLANAR") == nullptr) {  // experiment switch (profiles/)
+      if (!PlanarizeInput(g, io, blocks, false, st, &ioL, error)) {
+        return false;
+      }
+    }
     for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {
       const std::size_t np = std::min<std::size_t>(chunk, pairs - p0);
       ClassMark(1, st, true);
-      if (!LaunchTiled(g, io, *tabs, work_[0], work_[1], work_[2], scratch_, static_cast<int>(p0 * channels_),
+      if (!LaunchTiled(g, ioL, *tabs, work_[0], work_[1], work_[2], scratch_, static_cast<int>(p0 * channels_),
                        static_cast<int>(np * channels_), st, error)) {
         return false;
       }
