@@ -20,7 +20,7 @@
 // lane-contiguous and a transform costs two round trips instead of four or five; the spectral product is never written.
 // Row transforms: Stockham autosort passes (the staged path's own index algebra, gen_pass_kernel) through ONE LDS buffer
 // (a pass reads, waits for every thread to have read, then writes), first pass from global memory, last pass to global
-// memory; LDS words are padded by one per sixteen so that the first pass's stride-R stores spread over the banks.
+// memory; LDS word indices are XOR-swizzled (tiled_pad) so that the first pass's stride-R stores spread over the banks.
 //
 // K1 = 16 (K = 32768 .. 131072: M2 = 2048 / 4096 / 8192) or 32 (K = 262144: M2 = 8192).
 #pragma once
@@ -86,14 +86,17 @@ MI_GLOBAL void tiled_load_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT tw
 }
 
 // ---- row transforms in LDS ------------------------------------------------------------------------------------------
-MI_HD constexpr int tiled_pad(int i) { return i + (i >> 4); }
+// LDS word index of row element i: the low four bits XORed with the next four -- the first pass's stride-R stores (lane j
+// writes words 16 j + u) and the later passes' 16-word groups both spread over all banks, and the buffer stays M2 words
+// (a padded layout, i + i/16, took 34.8 KB at M2 = 4096: four workgroups per CU instead of five)
+MI_HD constexpr int tiled_pad(int i) { return i ^ ((i >> 4) & 15); }
 template <int LOG2M>
 struct TiledRowCfg {
   static constexpr int M = 1 << LOG2M;
   static constexpr int T = M / 16;               // threads: sixteen points each in every pass
   static constexpr int R0 = 1 << (LOG2M % 4);    // first pass radix (1 = none: 4096 = 16^3)
   static constexpr int NPASS = LOG2M / 4 + (R0 > 1 ? 1 : 0);
-  static constexpr int BUF_WORDS = M + M / 16;   // padded
+  static constexpr int BUF_WORDS = M;            // swizzled, not padded (tiled_pad)
   // ONE buffer: a pass between LDS and LDS reads its sixteen words, waits for every thread to have read, then writes
   static constexpr int LDS_BYTES = BUF_WORDS * 8;
 };
@@ -266,6 +269,17 @@ MI_GLOBAL void tiled_store_kernel(Geometry g, const cf *MI_RESTRICT tw, const cf
   }
   dftR<+1, K1>(v);
   float *plane = planes + ip * g.Bp;
+  if ((g.Oc & 1) == 0) {
+    // even history length (every shipped geometry): a complex word is kept or dropped whole -- one 8-byte store
+    MI_UNROLL
+    for (int n1 = 0; n1 < K1; ++n1) {
+      const int n = 2 * (n1 * M2 + n2);  // compact samples n, n + 1
+      if (n >= g.Oc) {
+        *reinterpret_cast<cf *>(plane + (n - g.Oc)) = v[out_pos<K1>(n1)];
+      }
+    }
+    return;
+  }
   MI_UNROLL
   for (int n1 = 0; n1 < K1; ++n1) {
     const int n = 2 * (n1 * M2 + n2);  // compact samples n, n + 1
