@@ -1521,7 +1521,8 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
   // One sub-batch (the reference's own call shape: one block per call) has nothing to overlap: copy in, kernels and copy
   // out follow each other on the engine's stream, without the three cross-stream events of the pipelined form
   // (mi_ups_process_block p50 132 -> see profiles/r03_n_step_overhead.txt).
-  const bool oneStream = nsub == 1 && std::getenv("MIUPS_EXP_HOST_THREE_STREAMS") == nullptr;  // experiment switch (profiles/)
+  const bool oneStream = nsub == 1 && hostOneStream_ &&
+                         std::getenv("MIUPS_EXP_HOST_THREE_STREAMS") == nullptr;  // experiment switch (profiles/)
   if (oneStream) {
     h2d = d2h = own;
   }

@@ -164,6 +164,7 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
       if (!s->engine) {
         return nullptr;
       }
+      s->engine->SetHostOneStream(false);  // workers run side by side: see Engine::SetHostOneStream
     }
     m->slots_.push_back(std::move(s));
   }
