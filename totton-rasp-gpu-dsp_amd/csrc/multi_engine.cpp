@@ -164,7 +164,9 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
       if (!s->engine) {
         return nullptr;
       }
-      s->engine->SetHostOneStream(false);  // workers run side by side: see Engine::SetHostOneStream
+      if (std::getenv("MIUPS_EXP_MULTI_ONE_STREAM") == nullptr) {  // experiment switch (scripts/multi_stress.py)
+        s->engine->SetHostOneStream(false);  // workers run side by side: see Engine::SetHostOneStream
+      }
     }
     m->slots_.push_back(std::move(s));
   }
