@@ -28,11 +28,12 @@
 #include <type_traits>
 #include <vector>
 
-#include "device/kernel_fused.h"
 #include "device/kernels_generic.h"
 #include "device/kernels_tiled.h"
 #include "host/filter_config.h"
 #include "host/spectrum.h"
+
+#include "emu_launch.h"
 
 namespace miups_emu {
 thread_local Dim3 t_threadIdx;
@@ -133,53 +134,6 @@ cf *EmuFft(cf *a, cf *b, const cf *tw, int log2k, long long rows) {
   return src;
 }
 
-template <int LOG2K>
-void EmuFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, nullptr, t.Wself};
-  if constexpr (LOG2K >= 10) {
-    if (t.fusedNarrow) {  // one butterfly per thread (experiment form, EMU_NARROW)
-      using CfgN = FusedCfg<LOG2K, 1>;
-      if (io.ext_epilogue) {
-        miups_emu::launch(items, CfgN::T, CfgN::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 1>(g, io, ft); });
-      } else {
-        miups_emu::launch(items, CfgN::T, CfgN::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 1>(g, io, ft); });
-      }
-      return;
-    }
-  }
-  using Cfg = FusedCfg<LOG2K, 2, false>;
-  if constexpr (fused_plan_r32_exists(LOG2K, 2)) {
-    if (t.fusedR32) {  // radix-32 pass plan (experiment, EMU_R32)
-      if (io.ext_epilogue) {
-        miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 2, true>(g, io, ft); });
-      } else {
-        miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 2, true>(g, io, ft); });
-      }
-      return;
-    }
-  }
-  if (io.phase_parts > 1) {  // small-call form (EMU_PARTS): `items` counts workgroups = work items * phase_parts
-    if constexpr (LOG2K >= kPartsMinLog2K) {
-      miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_parts_kernel<LOG2K>(g, io, ft); });
-      return;
-    }
-    std::fprintf(stderr, "EMU_PARTS: no phase-split kernel for this transform length\n");
-    std::exit(2);
-  }
-  if (io.ext_epilogue) {
-    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, true, 2, false>(g, io, ft); });
-  } else {
-    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES, true, [&]() { fused_kernel<LOG2K, false, 2, false>(g, io, ft); });
-  }
-}
-
-template <int LOG2K>
-void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
-  using Cfg = FusedCfg<LOG2K>;
-  const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, t.selfW.data(), t.Wself};
-  miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
-}
-
 // interleave_tiled_kernel with the engine's 256-thread shape (EPT = rows * TI / 1024)
 template <int FMT, int TI>
 void EmuInterleaveTiledEpt(const Geometry &g, const IoDesc &io, const float *planes, int sb0, int nb, int tiles, int ept) {
@@ -214,25 +168,25 @@ void EmuInterleaveTiled(const Geometry &g, const IoDesc &io, const float *planes
 bool DispatchFused(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   if (t.fusedSplit) {  // two half-length transforms per block transform
     switch (g.log2k - 1) {
-      case 10: EmuFusedSplit<10>(g, io, t, items); return true;
-      case 11: EmuFusedSplit<11>(g, io, t, items); return true;
-      case 12: EmuFusedSplit<12>(g, io, t, items); return true;
-      case 13: EmuFusedSplit<13>(g, io, t, items); return true;
-      case 14: EmuFusedSplit<14>(g, io, t, items); return true;
+      case 10: EmuFusedSplitK10(g, io, t, items); return true;
+      case 11: EmuFusedSplitK11(g, io, t, items); return true;
+      case 12: EmuFusedSplitK12(g, io, t, items); return true;
+      case 13: EmuFusedSplitK13(g, io, t, items); return true;
+      case 14: EmuFusedSplitK14(g, io, t, items); return true;
       default: return false;
     }
   }
   switch (g.log2k) {
-    case 5: EmuFused<5>(g, io, t, items); return true;
-    case 6: EmuFused<6>(g, io, t, items); return true;
-    case 7: EmuFused<7>(g, io, t, items); return true;
-    case 8: EmuFused<8>(g, io, t, items); return true;
-    case 9: EmuFused<9>(g, io, t, items); return true;
-    case 10: EmuFused<10>(g, io, t, items); return true;
-    case 11: EmuFused<11>(g, io, t, items); return true;
-    case 12: EmuFused<12>(g, io, t, items); return true;
-    case 13: EmuFused<13>(g, io, t, items); return true;
-    case 14: EmuFused<14>(g, io, t, items); return true;
+    case 5: EmuFusedK5(g, io, t, items); return true;
+    case 6: EmuFusedK6(g, io, t, items); return true;
+    case 7: EmuFusedK7(g, io, t, items); return true;
+    case 8: EmuFusedK8(g, io, t, items); return true;
+    case 9: EmuFusedK9(g, io, t, items); return true;
+    case 10: EmuFusedK10(g, io, t, items); return true;
+    case 11: EmuFusedK11(g, io, t, items); return true;
+    case 12: EmuFusedK12(g, io, t, items); return true;
+    case 13: EmuFusedK13(g, io, t, items); return true;
+    case 14: EmuFusedK14(g, io, t, items); return true;
     default: return false;
   }
 }

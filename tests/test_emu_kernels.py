@@ -20,7 +20,7 @@ FMT = {"f32": 0, "s16": 1, "s24": 2, "s32": 3}
 
 @pytest.fixture(scope="session")
 def emu():
-    r = subprocess.run(["make", "-C", str(EMU_DIR)], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", str(EMU_DIR)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     return EMU_BIN
 

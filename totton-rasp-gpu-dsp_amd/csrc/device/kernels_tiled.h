@@ -20,7 +20,7 @@
 // lane-contiguous and a transform costs two round trips instead of four or five; the spectral product is never written.
 // Row transforms: Stockham autosort passes (the staged path's own index algebra, gen_pass_kernel) through ONE LDS buffer
 // (a pass reads, waits for every thread to have read, then writes), first pass from global memory, last pass to global
-// memory; LDS word indices are XOR-swizzled (tiled_pad) so that the first pass's stride-R stores spread over the banks.
+// memory; LDS word indices are XOR-swizzled (tiled_swz) so that the first pass's stride-R stores spread over the banks.
 //
 // K1 = 16 (K = 32768 .. 131072: M2 = 2048 / 4096 / 8192) or 32 (K = 262144: M2 = 8192).
 #pragma once
@@ -89,14 +89,14 @@ MI_GLOBAL void tiled_load_kernel(Geometry g, IoDesc io, const cf *MI_RESTRICT tw
 // LDS word index of row element i: the low four bits XORed with the next four -- the first pass's stride-R stores (lane j
 // writes words 16 j + u) and the later passes' 16-word groups both spread over all banks, and the buffer stays M2 words
 // (a padded layout, i + i/16, took 34.8 KB at M2 = 4096: four workgroups per CU instead of five)
-MI_HD constexpr int tiled_pad(int i) { return i ^ ((i >> 4) & 15); }
+MI_HD constexpr int tiled_swz(int i) { return i ^ ((i >> 4) & 15); }
 template <int LOG2M>
 struct TiledRowCfg {
   static constexpr int M = 1 << LOG2M;
   static constexpr int T = M / 16;               // threads: sixteen points each in every pass
   static constexpr int R0 = 1 << (LOG2M % 4);    // first pass radix (1 = none: 4096 = 16^3)
   static constexpr int NPASS = LOG2M / 4 + (R0 > 1 ? 1 : 0);
-  static constexpr int BUF_WORDS = M;            // swizzled, not padded (tiled_pad)
+  static constexpr int BUF_WORDS = M;            // swizzled, not padded (tiled_swz)
   // ONE buffer: a pass between LDS and LDS reads its sixteen words, waits for every thread to have read, then writes
   static constexpr int LDS_BYTES = BUF_WORDS * 8;
 };
@@ -116,7 +116,8 @@ struct TiledRow {
   static constexpr int M = Cfg::M, T = Cfg::T, R0 = Cfg::R0;
 
   // this workgroup's rows, as workgroup-uniform pointers (scalar registers): the per-element address is then one 32-bit
-  // offset (the indexed form, (it * K1 + k1) * M + i in 64 bits per element, was ~40 % of the kernel's VALU instructions)
+  // offset instead of (it * K1 + k1) * M + i in 64 bits per element (fewer instructions; the kernel's time did not move:
+  // profiles/r03_q_two_level.txt)
   struct Rows {
     const cf *x;    // plain: the row of A; spectral: the row of X
     const cf *xm;   // spectral: the mirror row of X (read backwards)
@@ -167,7 +168,7 @@ struct TiledRow {
         if constexpr (FROM_GLOBAL) {
           v[b][t] = fetch(rows, i);
         } else {
-          v[b][t] = lds[tiled_pad(i)];
+          v[b][t] = lds[tiled_swz(i)];
         }
       }
     }
@@ -188,7 +189,7 @@ struct TiledRow {
         if constexpr (TO_GLOBAL) {
           dst[base + u * NS] = v[b][out_pos<R>(u)];
         } else {
-          lds[tiled_pad(base + u * NS)] = v[b][out_pos<R>(u)];
+          lds[tiled_swz(base + u * NS)] = v[b][out_pos<R>(u)];
         }
       }
     }
@@ -218,10 +219,6 @@ struct TiledRow {
     } else {
       pass<16, 1, true, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
-      if constexpr (Cfg::NPASS == 4) {  // M = 65536 would be; kept for symmetry
-        pass<16, 16, false, false>(rows, tw, lds, nullptr, tid);
-        MI_SYNC();
-      }
       pass<16, M / 256, false, false>(rows, tw, lds, nullptr, tid);
       MI_SYNC();
       pass<16, M / 16, false, true>(rows, tw, lds, dst, tid);
