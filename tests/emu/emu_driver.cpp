@@ -79,20 +79,26 @@ void launch(unsigned grid, unsigned block, size_t shmem, bool barriers, const st
       }
       continue;
     }
+    // one OS thread per GPU thread, kept for ALL workgroups of the launch (a thread per (workgroup, thread) spent most of
+    // the suite's time in clone/join): every thread walks the workgroups in order, a barrier between two workgroups
     pthread_barrier_init(&g_bar, nullptr, block);
     std::vector<std::thread> threads;
     threads.reserve(block);
     for (unsigned t = 0; t < block; ++t) {
-      threads.emplace_back([&, b, t]() {
-        t_blockIdx.x = b;
-        t_threadIdx.x = t;
-        f();
+      threads.emplace_back([&, t]() {
+        for (unsigned wg = 0; wg < grid; ++wg) {
+          t_blockIdx.x = wg;
+          t_threadIdx.x = t;
+          f();
+          pthread_barrier_wait(&g_bar);  // the workgroup is done: its LDS may be reused
+        }
       });
     }
     for (auto &th : threads) {
       th.join();
     }
     pthread_barrier_destroy(&g_bar);
+    break;
   }
 }
 }  // namespace miups_emu
