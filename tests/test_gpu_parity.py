@@ -586,3 +586,38 @@ def test_640k_tap_filters_take_the_two_level_path(ups, O, gpu, tmp_path, monkeyp
         tol = lsb + 1e-5 * np.abs(truth).max()
         assert np.abs(y[:, c] - truth).max() <= tol
         assert np.abs(y[:, c] - y_old[:, c]).max() <= 2 * tol
+
+
+def test_two_level_path_with_eq_folded_in(ups, O, gpu, tmp_path):
+    """mi_filter_set_eq on a 640k-tap filter: the two-level path's own copies of the spectrum tables ([k1][k2] order) are
+    rebuilt with the EQ response folded in. 8x, two channels, two calls, against the fp64 statement of H_fir * EQ on the
+    N-point grid (the same truth the fused path's EQ tests use); and back to the plain filter afterwards."""
+    import json
+
+    sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
+    import filter_design as fd
+
+    ratio, channels, blocks = 8, 2, 2
+    h = fd.design(640_000, ratio, "48k", "linear")
+    path = fd.export(h, tmp_path, fd.base_name("48k", ratio, 640_000, "linear"), ratio)
+    _, taps, fft, block, L = O.read_filter(path)
+    h32 = np.fromfile(str(path).replace(".json", ".bin"), "<f4")
+    eq_text = json.loads((ROOT / "tests" / "golden" / "g4_eq_profiles.json").read_text())["opra10"]
+    fs_out = 48000.0 * ratio
+    filt = ups.Filter(path, device=gpu)
+    filt.set_eq(eq_text, fs_out)
+    eng = ups.Engine(filt, 1, channels, ups.PCM_F32, ups.PCM_F32)
+    nin = block // L
+    x = (np.random.default_rng(77).standard_normal((2 * blocks * nin, channels)) * 0.1).astype(np.float32)
+    y = np.concatenate([eng.process_host(x[k * blocks * nin:(k + 1) * blocks * nin], blocks).view(np.float32)
+                        .reshape(blocks * block, channels) for k in range(2)])
+    assert eng.path == "staged" and eng.last_two_level
+    eq_half = O.eq_response(eq_text, fft // 2 + 1, fft, fs_out)
+    for c in range(channels):
+        truth = O.eq_fused_stream_truth(x[:, c].astype(np.float64), h32, L, fft, block, 2 * blocks, eq_half).reshape(-1)
+        assert rel_err(y[:, c], truth) <= TOL_TRUTH
+    filt.set_eq("", fs_out)  # plain again: the next call takes the new tables (history restarted for a clean comparison)
+    eng.reset()
+    y0 = eng.process_host(x[:blocks * nin], blocks).view(np.float32).reshape(blocks * block, channels)
+    truth0 = O.truth_stream(x[:blocks * nin, 0].astype(np.float64), h32, L, blocks, block).reshape(-1)
+    assert rel_err(y0[:, 0], truth0) <= TOL_TRUTH
