@@ -296,7 +296,8 @@ int main(int argc, char **argv) {
       int parts = 0;
       if (const char *pp = std::getenv("EMU_PARTS")) {
         parts = std::atoi(pp);
-        if (parts < 2 || g.P % parts != 0 || t.fusedSplit || t.fusedNarrow || t.fusedR32) {
+        if (parts < 2 || (t.fusedSplit ? 2 * g.P : g.P) % parts != 0 || t.fusedNarrow || t.fusedR32 ||
+            (t.fusedSplit && std::getenv("EMU_PARK"))) {
           std::fprintf(stderr, "EMU_PARTS: %d does not fit this geometry\n", parts);
           return 2;
         }

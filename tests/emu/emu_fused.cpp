@@ -55,6 +55,10 @@ template <int LOG2K>
 void EmuFusedSplit(const Geometry &g, const IoDesc &io, const FilterTables &t, unsigned items) {
   using Cfg = FusedCfg<LOG2K>;
   const FusedTables ft{t.tw.data(), t.WmT.data(), t.blockB.data(), t.GT.data(), t.G0.data(), t.Wb, t.selfW.data(), t.Wself};
+  if (io.phase_parts > 1) {  // small-call form (EMU_PARTS): `items` counts workgroups
+    miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_parts_kernel<LOG2K>(g, io, ft); });
+    return;
+  }
   miups_emu::launch(items, Cfg::T, Cfg::LDS_BYTES_SPLIT, true, [&]() { fused_split_kernel<LOG2K>(g, io, ft); });
 }
 

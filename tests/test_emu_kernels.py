@@ -182,6 +182,36 @@ def test_emulated_phase_split_small_calls(emu, O, make_filter, tmp_path, monkeyp
             assert np.abs(got - truth).max() <= 1e-5 * np.abs(truth).max()
 
 
+@pytest.mark.parametrize("fft,taps,L,parts,channels", [
+    (4096, 1025, 1, 2, 1),   # K = 2048 as two 1024-point halves; P = 1: the two halves of the one phase on two workgroups
+    (8192, 2049, 2, 4, 2),   # P = 2: four workgroups, one half transform each; stereo
+    (8192, 2049, 2, 2, 1),   # ... two workgroups, one phase (both halves) each
+])
+def test_emulated_split_form_small_calls(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, parts, channels):
+    """fused_split_parts_kernel: the split form's 2P half transforms of a channel-block spread over `parts` workgroups,
+    bit-identical to fused_split_kernel with the same group width, and against fp64 truth."""
+    monkeypatch.setenv("EMU_SPLIT", "1")
+    rng = np.random.default_rng(fft + parts)
+    h = rng.standard_normal(taps).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    blocks, calls = 2, 2
+    x = rng.standard_normal((calls, 1, blocks * nin, channels)).astype(np.float32)
+    monkeypatch.setenv("EMU_PARTS", str(parts))
+    split = run_emu(emu, tmp_path, p, x.tobytes(), 1, channels, blocks, calls, "fused")
+    monkeypatch.delenv("EMU_PARTS")
+    monkeypatch.setenv("EMU_CG", "1")
+    plain = run_emu(emu, tmp_path, p, x.tobytes(), 1, channels, blocks, calls, "fused")
+    assert split == plain
+    y = np.frombuffer(split, np.float32).reshape(calls, 1, blocks * block, channels)
+    for c in range(channels):
+        xs = np.concatenate([x[k, 0, :, c] for k in range(calls)])
+        truth = O.truth_stream(xs, h, L, calls * blocks, block).reshape(-1)
+        got = np.concatenate([y[k, 0, :, c] for k in range(calls)])
+        assert np.abs(got - truth).max() <= 1e-5 * np.abs(truth).max()
+
+
 @pytest.mark.parametrize("fft,taps,L,path,streams,channels,blocks,calls", R32_CASES)
 def test_emulated_radix32_plan(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, path, streams, channels, blocks,
                                calls):

@@ -196,6 +196,9 @@ def test_forced_serial_chunks(ups, O, hip, gpu, monkeypatch, fname, streams, cha
     ("filter_48k_16x_80000_min_phase", 1, 8, 2, 16),  # P = 16, 16 items x 16 parts = 256 workgroups (K = 4096), planar input
     ("filter_48k_8x_160000_linear_phase", 2, 3, 5, 8),  # 30 items x 8 parts; odd channel count
     ("filter_48k_16x_80000_min_phase", 3, 2, 7, 4),   # 42 items: of P = 16's divisors 4 is the largest that fits (42 x 4 <= 256)
+    ("filter_44k_2x_80000_min_phase", 1, 1, 1, 4),    # split form (K = 32768 as two halves): its 2P = 4 half transforms on 4 workgroups
+    ("filter_44k_2x_80000_min_phase", 2, 2, 9, 4),    # ... 36 items x 4; stereo through the split-planar timeline
+    ("filter_48k_2x_80000_min_phase", 1, 2, 40, 2),   # 80 items: two workgroups each (one phase = both halves)
 ])
 def test_small_calls_split_their_phases_over_workgroups(ups, O, hip, gpu, monkeypatch, fname, streams, channels, blocks, parts):
     """Calls with far fewer work items than CUs take fused_parts_kernel (several workgroups per channel-block, P / parts

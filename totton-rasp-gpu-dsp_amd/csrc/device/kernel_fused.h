@@ -1911,8 +1911,11 @@ struct FusedKernel {
       MI_SCHED_FENCE();
     }
   }
+  // PARTS: only half transforms [itLo, itHi) of the 2P (phase, half) pairs below (fused_split_parts_kernel)
+  template <bool PARTS = false>
   static MI_DEVICE void channel_block_split(const Geometry &g, const IoDesc &io, BlockIo b, float *scr_c,
-                                            const FusedTables &ft, cf *lds, int tid, int cc, f4 *park) {
+                                            const FusedTables &ft, cf *lds, int tid, int cc, f4 *park, int itLo = 0,
+                                            int itHi = 0) {
     constexpr int kFirstMidStride = (R0 > 1) ? S0 / 16 : S0 / 256;
     const int sb = 64 * (cc & 1);  // stamp slot base (diagnostic builds)
     (void)sb;
@@ -1958,8 +1961,9 @@ struct FusedKernel {
       quad_split(xch[sl.srcK], xch[sl.srcM], xch[32 + sl.srcK], xch[32 + sl.srcM], Ws, Xs[0], Xs[1], Xs[2], Xs[3]);
     }
     MI_STAMP(sb + 8);
-    const int rot = (MI_BID_X >> 3) + cc;
-    for (int it = 0; it < 2 * g.P; ++it) {
+    const int rot = PARTS ? cc : (MI_BID_X >> 3) + cc;
+    const int itFirst = PARTS ? itLo : 0, itEnd = PARTS ? itHi : 2 * g.P;
+    for (int it = itFirst; it < itEnd; ++it) {
       const int p = ((it >> 1) + rot) % g.P, h = it & 1;
       const f4 *gt = ft.GT + static_cast<long long>(p) * 32 * T;
       const f4 *g0 = ft.G0 + p * (2 * kSelfLanes);
@@ -2049,9 +2053,11 @@ struct FusedKernel {
 #endif
     int unit = local, pLo = 0, pHi = 0;
     if constexpr (PARTS) {
+      // the split form's unit of division is the half transform: 2P of them per channel-block
+      const int pieces = (SPLIT ? 2 * g.P : g.P) / io.phase_parts;
       unit = local / io.phase_parts;
-      pLo = (local - unit * io.phase_parts) * (g.P / io.phase_parts);
-      pHi = pLo + g.P / io.phase_parts;
+      pLo = (local - unit * io.phase_parts) * pieces;
+      pHi = pLo + pieces;
     }
     // item = (stream*groups + group) * blocks + block   (block fastest)
     const int item = io.item0 + unit;
@@ -2067,8 +2073,8 @@ struct FusedKernel {
       int tc = tid;  // fresh copy per channel: keeps address arithmetic inside the loop body
       MI_OPAQUE_VGPR(tc);
       if constexpr (SPLIT) {
-        f4 *park = io.park ? io.park + static_cast<long long>(local) * split_park_words(T) : nullptr;
-        channel_block_split(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, park);
+        f4 *park = (io.park && !PARTS) ? io.park + static_cast<long long>(local) * split_park_words(T) : nullptr;
+        channel_block_split<PARTS>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, park, pLo, pHi);
       } else {
         channel_block<EXT, PARTS>(g, io, b, scr + static_cast<long long>(cc) * g.P * g.Bp, ft, lds, tc, cc, pLo, pHi);
       }
@@ -2122,6 +2128,16 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 
                                                                                                             FusedTables ft) {
   MI_DYN_SHARED(cf, lds);
   FusedKernel<LOG2K, 2, false>::template run<true, true>(g, io, ft, lds);
+}
+
+// ... and its small-call form: io.phase_parts workgroups per channel-block, 2P / phase_parts half transforms each (each
+// repeats both forward halves)
+template <int LOG2K>
+MI_GLOBAL MI_LAUNCH_BOUNDS((FusedCfg<LOG2K>::T < 64 ? 64 : FusedCfg<LOG2K>::T), 2) void fused_split_parts_kernel(Geometry g,
+                                                                                                                  IoDesc io,
+                                                                                                                  FusedTables ft) {
+  MI_DYN_SHARED(cf, lds);
+  FusedKernel<LOG2K, 2, false>::template run<true, true, true>(g, io, ft, lds);
 }
 
 }  // namespace miups

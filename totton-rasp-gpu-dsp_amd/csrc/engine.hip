@@ -966,10 +966,14 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   // mi_ups_process_block at the headline filter: kernel 60 -> 2x us (profiles/r03_n_step_overhead.txt).
   parts_ = 0;
   const std::size_t units = blocks * static_cast<std::size_t>(streams_) * channels_;
-  if (!filter_->fusedSplit() && !narrow && !filter_->fusedR32() && g.log2k >= kPartsMinLog2K && g.log2k <= 14 &&
+  // the split form (K = 32768 as two halves) divides by half transforms: 2P pieces per channel-block; the parked-input
+  // experiment shares state between the two halves of a phase and keeps the plain form
+  const bool splitOk = filter_->fusedSplit() && g.log2k == 15 && std::getenv("MIUPS_EXP_PARK") == nullptr;
+  const int pieces = filter_->fusedSplit() ? 2 * g.P : g.P;
+  if ((splitOk || (!filter_->fusedSplit() && g.log2k >= kPartsMinLog2K && g.log2k <= 14)) && !narrow && !filter_->fusedR32() &&
       std::getenv("MIUPS_EXP_NO_PHASE_PARTS") == nullptr) {  // experiment switch (profiles/)
-    for (int d = g.P; d >= 2; --d) {
-      if (g.P % d == 0 && units * static_cast<std::size_t>(d) <= static_cast<std::size_t>(cuCount_)) {
+    for (int d = pieces; d >= 2; --d) {
+      if (pieces % d == 0 && units * static_cast<std::size_t>(d) <= static_cast<std::size_t>(cuCount_)) {
         parts_ = d;
         break;
       }

@@ -103,6 +103,16 @@ bool LaunchFusedSplit(const Geometry &g, const IoDesc &io, const FusedTables &ft
                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES_SPLIT));
     attr_set[dev] = true;
   }
+  if (io.phase_parts > 1) {  // small calls: `items` counts workgroups = work items * phase_parts (a divisor of 2P)
+    static bool attr_parts[64] = {};
+    if (Cfg::LDS_BYTES_SPLIT > 64 * 1024 && dev < 64 && !attr_parts[dev]) {
+      MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_split_parts_kernel<LOG2K>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES_SPLIT));
+      attr_parts[dev] = true;
+    }
+    hipLaunchKernelGGL((fused_split_parts_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io, ft);
+    return HipOk(hipGetLastError(), "fused_split_parts_kernel launch", error);
+  }
   hipLaunchKernelGGL((fused_split_kernel<LOG2K>), dim3(items), dim3(Cfg::T), Cfg::LDS_BYTES_SPLIT, st, g, io, ft);
   return HipOk(hipGetLastError(), "fused_split_kernel launch", error);
 }
