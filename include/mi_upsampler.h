@@ -182,6 +182,9 @@ unsigned long long mi_engine_last_generation(const mi_engine *e);
 /* test hook: the next table upload of this filter fails after the host-side build (tests that a failed EQ change
  * leaves the filter usable) */
 void mi_debug_fail_next_table_upload(mi_filter *f);
+/* diagnostic: on SIGABRT print the native stack of the aborting thread to stderr, then continue to the previous handler
+ * (the HIP runtime aborts without a message on some internal failures) */
+void mi_debug_install_abort_backtrace(void);
 
 /* Timing of the dominant kernel(s) on the stream they run on: with slots > 0
  * every process call brackets its main kernel(s) with a hipEvent pair (ring of

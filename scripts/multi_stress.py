@@ -1,7 +1,7 @@
 """Host-side stress of MultiEngine's worker threads (no GPU fault involved: the question is a silent SIGABRT inside the HIP
 runtime seen once in tests/test_gpu_stream_host.py::test_time_split_is_bit_identical_to_one_engine[4 slots, 2 streams, 8 ch]).
 Repeats that scenario N times in one process and checks every result against one engine.
-usage: multi_stress.py [rounds]      env MIUPS_EXP_MULTI_ONE_STREAM=1 puts the workers' engines on the one-stream host path"""
+usage: multi_stress.py [rounds]      env MIUPS_EXP_MULTI_THREE_STREAMS=1 puts the workers' engines on the three-stream host path without the small-call kernels"""
 import os, sys, time
 from pathlib import Path
 import numpy as np
@@ -26,4 +26,4 @@ for r in range(rounds):
     multi.reset()
     one.reset()
     print(f"round {r} ok ({time.time() - t0:.1f} s)", flush=True)
-print("done", "one-stream workers" if os.environ.get("MIUPS_EXP_MULTI_ONE_STREAM") else "three-stream workers")
+print("done", "three-stream workers" if os.environ.get("MIUPS_EXP_MULTI_THREE_STREAMS") else "default workers")

@@ -19,8 +19,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def ups():
+    import os
+
     import totton_rasp_gpu_dsp_amd as m
 
+    if os.environ.get("MIUPS_ABORT_BACKTRACE"):  # diagnostic: native stack of a thread that calls abort() (HIP runtime)
+        m.lib.mi_debug_install_abort_backtrace()
     return m
 
 

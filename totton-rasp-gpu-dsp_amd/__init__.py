@@ -121,6 +121,7 @@ def _load():
         "mi_engine_set_kernel_timing_stride": (i32, [vp, i32]),
         "mi_engine_last_phase_parts": (i32, [vp]),
         "mi_engine_last_two_level": (i32, [vp]),
+        "mi_debug_install_abort_backtrace": (None, []),
         "mi_engine_last_kernel_ms": (dbl, [vp]),
         "mi_engine_kernel_ms_stats": (i32, [vp, f64p, f64p, f64p, C.POINTER(i32)]),
         "mi_opra_to_apo": (i32, [C.c_char_p, i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
@@ -198,7 +199,7 @@ EXPORTED_SYMBOLS = [
     "mi_engine_in_frames_per_block", "mi_engine_out_frames_per_block", "mi_engine_path", "mi_engine_process_device",
     "mi_engine_process_host", "mi_host_alloc", "mi_host_free", "mi_host_register", "mi_host_unregister",
     "mi_device_copy_rate", "mi_engine_rebind", "mi_filter_generation",
-    "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_set_kernel_timing_stride", "mi_engine_last_phase_parts", "mi_engine_last_two_level", "mi_engine_last_kernel_ms",
+    "mi_engine_last_generation", "mi_debug_fail_next_table_upload", "mi_engine_enable_kernel_timing", "mi_engine_set_kernel_timing_stride", "mi_engine_last_phase_parts", "mi_engine_last_two_level", "mi_debug_install_abort_backtrace", "mi_engine_last_kernel_ms",
     "mi_engine_kernel_ms_stats", "mi_engine_enable_class_timing", "mi_engine_last_class_ms", "mi_opra_to_apo", "mi_multi_create", "mi_multi_destroy", "mi_multi_set_eq", "mi_multi_reset",
     "mi_multi_process_host", "mi_multi_in_frames_per_block", "mi_multi_out_frames_per_block",
     "mi_multi_device_of_stream", "mi_multi_partition", "mi_multi_device_of_channel", "mi_multi_partition_channels",

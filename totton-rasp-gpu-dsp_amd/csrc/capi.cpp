@@ -2,7 +2,12 @@
 // failure leaves a message in the thread-local last-error slot.
 #include "../../include/mi_upsampler.h"
 
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -476,6 +481,38 @@ int mi_engine_rebind(mi_engine *e, mi_filter *f, int reset_history) {
 unsigned long long mi_filter_generation(const mi_filter *f) { return f ? f->filter->generation() : 0; }
 
 unsigned long long mi_engine_last_generation(const mi_engine *e) { return e ? e->engine->lastGeneration() : 0; }
+
+// Diagnostic: print the native stack of the thread that raises SIGABRT (the HIP runtime aborts without a message in some
+// internal failures; Python's faulthandler only knows Python frames), then let the previous handler (or the default) run.
+namespace {
+struct sigaction g_prevAbort;
+int g_abortFd = 2;
+void AbortBacktrace(int sig) {
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n== native backtrace of the aborting thread ==\n";
+  (void)!write(g_abortFd, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, g_abortFd);
+  sigaction(SIGABRT, &g_prevAbort, nullptr);
+  raise(sig);
+}
+}  // namespace
+void mi_debug_install_abort_backtrace(void) {
+  // MIUPS_ABORT_BACKTRACE=<path>: where to write (a test runner may have redirected descriptor 2); anything else: stderr
+  if (const char *path = std::getenv("MIUPS_ABORT_BACKTRACE")) {
+    if (path[0] == '/' || path[0] == '.' ) {
+      const int fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+      if (fd >= 0) {
+        g_abortFd = fd;
+      }
+    }
+  }
+  struct sigaction sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = AbortBacktrace;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGABRT, &sa, &g_prevAbort);
+}
 
 void mi_debug_fail_next_table_upload(mi_filter *f) {
   if (f) {

@@ -143,11 +143,10 @@ class Engine {
   bool EnableTiming(int slots, std::string *error);
   // every n-th process call carries the event pair (n >= 1): a pair costs ~8 us of stream time at the headline shape
   // (scripts/step_overhead.py, profiles/r03_n_step_overhead.txt), a timed region may not want it on every call
-  // ProcessHost of a single sub-batch on the engine's own stream (default) or through the three-stream pipeline. Engines
-  // that run on worker threads next to each other (MultiEngine) keep the pipeline: one full GPU suite in four aborted
-  // inside the HIP runtime (SIGABRT, no message, no GPU fault) with four workers in the one-stream form, none of the
-  // ~20 before it in the three-stream form (gpurun_out/w_tests.log; cause not established).
+  // ProcessHost of a single sub-batch on the engine's own stream (default) or through the three-stream pipeline; the
+  // phase-split kernels for small calls (PickChannelGroup) on or off. Test / experiment hooks: both default to on.
   void SetHostOneStream(bool on) { hostOneStream_ = on; }
+  void SetSmallCallSplit(bool on) { smallCallSplit_ = on; }
   // workgroups per (block, stream, channel) of the latest fused call: 0 = the plain form, >= 2 = phase-split (small calls)
   int lastPhaseParts() const { return parts_; }
   // the latest staged call ran the two-level transforms (device/kernels_tiled.h) rather than one launch per pass
@@ -185,6 +184,7 @@ class Engine {
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
   bool hostOneStream_ = true;
+  bool smallCallSplit_ = true;
   bool lastTwoLevel_ = false;
   int parts_ = 0;                  // fused path, small calls: workgroups per (block, stream, channel) (phase-split), else 0
   std::size_t wgCapacity_ = 256;   // fused path: workgroups resident on the whole chip at once

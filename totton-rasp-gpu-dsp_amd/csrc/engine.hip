@@ -385,7 +385,11 @@ bool FillArray(T **dst, std::size_t *count, const std::vector<T> &src, hipStream
     *count = n;
   }
   if (!src.empty()) {
+    // ONE copy from pageable memory in flight at a time: the runtime pins such a source on the fly and maps it for the
+    // copy engine at its host address; two in-flight copies whose sources share a page (neighbouring heap vectors) collide
+    // when the first one is unpinned -- "Memory access fault by GPU ... on address <host page>" (profiles/r03_r_multi_fault.txt)
     MI_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));
   }
   return true;
 }
@@ -862,6 +866,9 @@ bool Engine::LoadHistoryHost(const void *h, std::size_t streamStride, std::strin
     MI_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_]) + static_cast<std::size_t>(s) * histStride_,
                           static_cast<const char *>(h) + static_cast<std::size_t>(s) * streamStride, histStride_,
                           hipMemcpyHostToDevice, own));
+    if (streams_ > 1) {
+      MI_HIP(hipStreamSynchronize(own));  // neighbouring rows of a pageable buffer: one copy in flight (see FillArray)
+    }
   }
   if (!MarkDone(own_, nullptr, error)) {
     return false;
@@ -971,7 +978,7 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   const bool splitOk = filter_->fusedSplit() && g.log2k == 15 && std::getenv("MIUPS_EXP_PARK") == nullptr;
   const int pieces = filter_->fusedSplit() ? 2 * g.P : g.P;
   if ((splitOk || (!filter_->fusedSplit() && g.log2k >= kPartsMinLog2K && g.log2k <= 14)) && !narrow && !filter_->fusedR32() &&
-      std::getenv("MIUPS_EXP_NO_PHASE_PARTS") == nullptr) {  // experiment switch (profiles/)
+      smallCallSplit_ && std::getenv("MIUPS_EXP_NO_PHASE_PARTS") == nullptr) {  // experiment switch (profiles/)
     for (int d = pieces; d >= 2; --d) {
       if (pieces % d == 0 && units * static_cast<std::size_t>(d) <= static_cast<std::size_t>(cuCount_)) {
         parts_ = d;
@@ -1521,6 +1528,51 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     stageInBytes_ = inRow * streams_;
     stageOutBytes_ = outRow * streams_;
   }
+  // A call that issues several copies per buffer (streams are rows of the caller's buffers, sub-batches are pieces of the
+  // rows) must not leave them to the runtime's on-the-fly pinning when the buffers are pageable: in-flight copies whose host
+  // ranges share a page collide (see FillArray; the first sighting was a two-stream engine, profiles/r03_r_multi_fault.txt).
+  // The buffers are page-locked here for the duration of the call -- one registration each, released after the last copy
+  // has completed -- unless they already are (mi_host_alloc, mi_host_register, MultiEngine); if the registration is
+  // refused, every copy is waited for before the next one is issued.
+  struct ScopedPin {
+    void *p = nullptr;
+    ~ScopedPin() {
+      if (p) {
+        (void)hipHostUnregister(p);
+      }
+    }
+  } pinIn, pinOut;
+  bool serialCopies = false;
+  if (streams_ > 1 || nsub > 1) {
+    auto pageLocked = [](const void *p) {
+      hipPointerAttribute_t a;
+      if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      return a.type == hipMemoryTypeHost;
+    };
+    const std::size_t inExtent = (static_cast<std::size_t>(streams_) - 1) * inStride + blocks * inBlockHost -
+                                 (pitchedIn ? inFramePitch - inFrame : 0);
+    const std::size_t outExtent = (static_cast<std::size_t>(streams_) - 1) * outStride + blocks * outBlockHost -
+                                  (pitchedOut ? outFramePitch - outFrame : 0);
+    if (!packIn && !pageLocked(hIn)) {
+      if (hipHostRegister(const_cast<void *>(hIn), inExtent, hipHostRegisterDefault) == hipSuccess) {
+        pinIn.p = const_cast<void *>(hIn);
+      } else {
+        (void)hipGetLastError();
+        serialCopies = true;
+      }
+    }
+    if (!packOut && !pageLocked(hOut)) {
+      if (hipHostRegister(hOut, outExtent, hipHostRegisterDefault) == hipSuccess) {
+        pinOut.p = hOut;
+      } else {
+        (void)hipGetLastError();
+        serialCopies = true;
+      }
+    }
+  }
   hipStream_t own = static_cast<hipStream_t>(own_), h2d = static_cast<hipStream_t>(h2d_), d2h = static_cast<hipStream_t>(d2h_);
   // One sub-batch (the reference's own call shape: one block per call) has nothing to overlap: copy in, kernels and copy
   // out follow each other on the engine's stream, without the three cross-stream events of the pipelined form
@@ -1562,6 +1614,9 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
         MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow,
                               static_cast<const char *>(hIn) + s * inStride + b0 * inBlock, nb * inBlock,
                               hipMemcpyHostToDevice, h2d));
+      }
+      if (serialCopies && !packIn) {
+        MI_HIP(hipStreamSynchronize(h2d));
       }
     }
     if (!oneStream) {
@@ -1606,6 +1661,9 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
         MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlock,
                               static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock,
                               hipMemcpyDeviceToHost, d2h));
+      }
+      if (serialCopies && !packOut) {
+        MI_HIP(hipStreamSynchronize(d2h));
       }
     }
     if (!oneStream) {

@@ -100,6 +100,11 @@ MultiEngine::~MultiEngine() {
     if (s->worker.joinable()) {
       s->worker.join();
     }
+    if (s->context) {
+      (void)hipSetDevice(s->device);
+      HostFree(s->context);
+      s->context = nullptr;
+    }
   }
 }
 
@@ -164,8 +169,9 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
       if (!s->engine) {
         return nullptr;
       }
-      if (std::getenv("MIUPS_EXP_MULTI_ONE_STREAM") == nullptr) {  // experiment switch (scripts/multi_stress.py)
-        s->engine->SetHostOneStream(false);  // workers run side by side: see Engine::SetHostOneStream
+      if (std::getenv("MIUPS_EXP_MULTI_THREE_STREAMS") != nullptr) {  // experiment switch (scripts/multi_stress.py)
+        s->engine->SetHostOneStream(false);
+        s->engine->SetSmallCallSplit(false);
       }
     }
     m->slots_.push_back(std::move(s));
@@ -174,7 +180,12 @@ std::unique_ptr<MultiEngine> MultiEngine::Create(const std::vector<int> &devices
     m->histBytes_ = m->slots_[0]->engine->histFrames() * static_cast<std::size_t>(channels) * pcm_bytes(inFmt);
     m->tail_.assign(m->histBytes_ * static_cast<std::size_t>(streams), 0);
     for (auto &s : m->slots_) {
-      s->context.assign(m->tail_.size(), 0);
+      (void)hipSetDevice(s->device);
+      s->context = static_cast<char *>(HostAlloc(std::max<std::size_t>(m->tail_.size(), 1), error));
+      if (!s->context) {
+        return nullptr;
+      }
+      std::memset(s->context, 0, m->tail_.size());
     }
   }
   for (auto &s : m->slots_) {
@@ -220,6 +231,10 @@ void MultiEngine::WorkerMain(Slot *slot) {
     }
     bool ok = true;
     std::string err;
+    std::unique_lock<std::mutex> turn(serialMu_, std::defer_lock);
+    if (job.serial) {
+      turn.lock();
+    }
     if (slot->engine) {
       const std::size_t G = slots_.size();
       if (split_ == kSplitTime) {
@@ -233,7 +248,7 @@ void MultiEngine::WorkerMain(Slot *slot) {
           const std::size_t frameOut = static_cast<std::size_t>(channels_) * pcm_bytes(outFmt_);
           const std::size_t startBytes = b0 * static_cast<std::size_t>(g.n_in) * frameIn;  // of the range, inside the call
           for (int st = 0; st < streams_ && histBytes_ > 0; ++st) {
-            char *dst = slot->context.data() + static_cast<std::size_t>(st) * histBytes_;
+            char *dst = slot->context + static_cast<std::size_t>(st) * histBytes_;
             const char *in = static_cast<const char *>(job.hIn) + static_cast<std::size_t>(st) * job.inStride;
             const std::size_t fromCall = std::min(startBytes, histBytes_);   // newest part: the call's own frames
             const std::size_t fromTail = histBytes_ - fromCall;              // oldest part: end of the previous call's tail
@@ -242,7 +257,7 @@ void MultiEngine::WorkerMain(Slot *slot) {
             }
             std::memcpy(dst + fromTail, in + startBytes - fromCall, fromCall);
           }
-          ok = (histBytes_ == 0 || slot->engine->LoadHistoryHost(slot->context.data(), histBytes_, &err)) &&
+          ok = (histBytes_ == 0 || slot->engine->LoadHistoryHost(slot->context, histBytes_, &err)) &&
                slot->engine->ProcessHost(static_cast<const char *>(job.hIn) + startBytes, job.inStride,
                                          static_cast<char *>(job.hOut) + b0 * static_cast<std::size_t>(g.B) * frameOut,
                                          job.outStride, b1 - b0, &err);
@@ -293,9 +308,43 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
       return false;
     }
   }
+  // The workers copy DIFFERENT sub-ranges of the caller's two buffers at the same time. From pageable memory that is not
+  // safe on this runtime: an asynchronous copy pins its host range on the fly, and two threads whose ranges share pages (or
+  // a later copy that meets a cached pin of another sub-range) ended in "Memory access fault by GPU ... on address <host
+  // page>" -- about one run of the GPU suite in four, always in the block-range partition (adjacent ranges of one buffer;
+  // gpurun_out/r1.log, native stack in abort_bt.txt: the HSA runtime's fault handler). So buffers that are not page-locked
+  // already (mi_host_alloc / mi_host_register) are registered here for the duration of the call; if that is refused
+  // (locked-memory limit, a partly registered range) the slots run one after the other instead.
+  const std::size_t inBytes = (static_cast<std::size_t>(streams_) - 1) * inStride +
+                              blocks * static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
+  const std::size_t outBytes = (static_cast<std::size_t>(streams_) - 1) * outStride +
+                               blocks * static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
+  auto pageLocked = [](const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return a.type == hipMemoryTypeHost;
+  };
+  (void)hipSetDevice(slots_[0]->device);
+  bool regIn = false, regOut = false, serial = false;
+  if (slots_.size() > 1) {
+    if (!pageLocked(hIn)) {
+      regIn = hipHostRegister(const_cast<void *>(hIn), inBytes, hipHostRegisterPortable) == hipSuccess;
+      serial = !regIn;
+    }
+    if (!pageLocked(hOut)) {
+      regOut = hipHostRegister(hOut, outBytes, hipHostRegisterPortable) == hipSuccess;
+      serial = serial || !regOut;
+    }
+    if (serial) {
+      (void)hipGetLastError();
+    }
+  }
   {
     std::lock_guard<std::mutex> lock(mu_);
-    job_ = Job{hIn, hOut, inStride, outStride, blocks};
+    job_ = Job{hIn, hOut, inStride, outStride, blocks, serial};
     pending_ = static_cast<int>(slots_.size());
     for (auto &s : slots_) {
       s->hasJob = true;
@@ -304,6 +353,12 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
   cvJob_.notify_all();
   std::unique_lock<std::mutex> lock(mu_);
   cvDone_.wait(lock, [&] { return pending_ == 0; });
+  if (regIn) {
+    (void)hipHostUnregister(const_cast<void *>(hIn));
+  }
+  if (regOut) {
+    (void)hipHostUnregister(hOut);
+  }
   if (split_ == kSplitTime && histBytes_ > 0) {
     // what the next call's first ranges will need: the last hist_frames input frames of (tail ++ this call) per stream
     const std::size_t callBytes = blocks * static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);

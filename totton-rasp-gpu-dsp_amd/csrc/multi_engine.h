@@ -74,11 +74,14 @@ class MultiEngine {
     const void *hIn = nullptr;
     void *hOut = nullptr;
     std::size_t inStride = 0, outStride = 0, blocks = 0;
+    bool serial = false;  // caller buffers could not be page-locked for this call: the slots take turns (see ProcessHost)
   };
   struct Slot {
     int index = 0, device = 0, streams = 0;
     int c0 = 0, nch = 0;  // channel group (the whole frame under kSplitStreams / kSplitTime)
-    std::vector<char> context;  // kSplitTime: the slot's left context, [stream][hist_frames] frames
+    // kSplitTime: the slot's left context, [stream][hist_frames] frames. Page-locked (HostAlloc): it is uploaded on every
+    // call from a worker thread, and a pinned source is a plain DMA -- no on-the-fly pinning inside the runtime
+    char *context = nullptr;
     std::shared_ptr<DeviceFilter> filter;
     std::unique_ptr<Engine> engine;  // null when the slot has no unit (more slots than streams / channels)
     std::thread worker;
@@ -92,6 +95,7 @@ class MultiEngine {
   std::vector<std::unique_ptr<Slot>> slots_;
   int streams_ = 0, channels_ = 0, split_ = kSplitStreams, inFmt_ = 0, outFmt_ = 0;
   std::mutex mu_;
+  std::mutex serialMu_;  // Job::serial: one slot inside its engine at a time
   std::condition_variable cvJob_, cvDone_;
   Job job_;
   int pending_ = 0;
