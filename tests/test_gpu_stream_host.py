@@ -190,8 +190,10 @@ def test_failed_eq_rebuild_keeps_the_old_tables(ups, gpu):
 
 def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     """A thread streams 64-block calls back to back on its own HIP stream while the main thread swaps the EQ four
-    times. No call may take longer than a handful of normal calls: the swap uploads beside the live tables on a
-    private stream and never synchronises the device."""
+    times. A swap must not hold the stream up: it uploads beside the live tables on a private stream and never
+    synchronises the device. Judged on the calls that OVERLAP a swap: a swap that stalls the stream shows at every swap,
+    so at most one of the four may coincide with a slow call (the box has hiccups of 3-10 ms about once in 10 000 calls
+    whether or not a swap is running: scripts/eq_swap_stall.py)."""
     from bench import Hip
 
     hip = Hip()
@@ -202,7 +204,7 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     d_in, d_out = hip.malloc(eng.in_bytes(blocks)), hip.malloc(eng.out_bytes(blocks))
     hip.h2d(d_in, synth(1, blocks * eng.in_frames, 2))
     stream = hip.stream()
-    times, stop = [], threading.Event()
+    times, spans, stop = [], [], threading.Event()
 
     def run():
         hip.lib.hipSetDevice(gpu)
@@ -210,7 +212,9 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
             t0 = time.perf_counter()
             eng.process_device(d_in, d_out, blocks, stream)
             hip.check(hip.lib.hipStreamSynchronize(C.c_void_p(stream)), "sync")
-            times.append(time.perf_counter() - t0)
+            t1 = time.perf_counter()
+            times.append(t1 - t0)
+            spans.append((t0, t1))
 
     t = threading.Thread(target=run)
     t.start()
@@ -220,7 +224,7 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     for k in range(4):
         t0 = time.perf_counter()
         filt.set_eq(PROFILES["opra10"] if k % 2 == 0 else "", 705600.0)
-        swaps.append(time.perf_counter() - t0)
+        swaps.append((t0, time.perf_counter()))
         time.sleep(0.05)
     time.sleep(0.2)
     stop.set()
@@ -229,7 +233,11 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     hip.check(hip.lib.hipFree(d_out), "hipFree")
     assert n_before > 20 and len(times) > n_before + 20
     typical = float(np.median(times))
-    assert max(times[5:]) < 10 * typical + 5e-3, (max(times[5:]), typical, swaps)
+    limit = 10 * typical + 5e-3
+    stalled = [k for k, (a, b) in enumerate(swaps)
+               if any(t1 - t0 > limit for t0, t1 in spans[5:] if t1 >= a and t0 <= b)]
+    assert len(stalled) <= 1, (stalled, typical, [round(b - a, 4) for a, b in swaps])
+    assert max(times[5:]) < 0.25, max(times[5:])  # and nothing ever hangs
 
 
 def test_calls_on_alternating_streams_are_ordered_by_the_engine(ups, gpu):
