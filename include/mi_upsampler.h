@@ -214,8 +214,10 @@ int mi_engine_last_class_ms(mi_engine *e, double *out4);
  * the CPUs local to its device (sysfs local_cpulist). No data is exchanged between devices (reference: channels are
  * independent objects, alsa_streamer_main.cpp:247-250,536-553). A device may be listed twice (two slots on
  * one GPU). Creation fails with a message when a listed device is not visible.
- * Host buffers: pageable memory works at the runtime's staging speed; use mi_host_alloc memory, or pin your own buffer
- * ONCE with mi_host_register, for buffers that are passed again and again.
+ * Host buffers: use mi_host_alloc memory, or pin your own buffer ONCE with mi_host_register, for buffers that are passed
+ * again and again. Pageable buffers work too: the call page-locks them for its own duration (hipHostRegister) because the
+ * slots copy different ranges of them at the same time, which is not safe on pageable memory; when that is
+ * refused the slots run one after the other.
  * mi_multi_set_eq is all-or-nothing: every slot's new tables are built first and published together; when one build
  * fails no slot changes.
  */
