@@ -23,7 +23,17 @@ def ups():
 
     import totton_rasp_gpu_dsp_amd as m
 
-    if os.environ.get("MIUPS_ABORT_BACKTRACE"):  # diagnostic: native stack of a thread that calls abort() (HIP runtime)
+    # diagnostic: the native stack of a thread that calls abort() -- the HSA runtime does on a GPU memory fault, from a
+    # thread Python's faulthandler does not know, and its message goes to the descriptor pytest has captured
+    # (profiles/r03_r_multi_fault.txt). On a GPU box the record lands in gpurun_out/ unless MIUPS_ABORT_BACKTRACE says otherwise.
+    out = ROOT / "gpurun_out"
+    if not os.environ.get("MIUPS_ABORT_BACKTRACE") and m.device_count() > 0:
+        try:
+            out.mkdir(exist_ok=True)
+            os.environ["MIUPS_ABORT_BACKTRACE"] = str(out / "abort_backtrace.txt")
+        except OSError:
+            pass
+    if os.environ.get("MIUPS_ABORT_BACKTRACE"):
         m.lib.mi_debug_install_abort_backtrace()
     return m
 
