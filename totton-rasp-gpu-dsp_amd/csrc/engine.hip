@@ -385,9 +385,9 @@ bool FillArray(T **dst, std::size_t *count, const std::vector<T> &src, hipStream
     *count = n;
   }
   if (!src.empty()) {
-    // ONE copy from pageable memory in flight at a time: the runtime pins such a source on the fly and maps it for the
-    // copy engine at its host address; two in-flight copies whose sources share a page (neighbouring heap vectors) collide
-    // when the first one is unpinned -- "Memory access fault by GPU ... on address <host page>" (profiles/r03_r_multi_fault.txt)
+    // ONE copy from pageable memory in flight at a time: several in flight whose sources share a page (neighbouring heap
+    // vectors) ended in "Memory access fault by GPU ... on address <host page>" -- as if the runtime pinned and mapped each
+    // source for its own copy and the shared page went with the first to complete (profiles/r03_r_multi_fault.txt)
     MI_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
     MI_HIP(hipStreamSynchronize(st));
   }
