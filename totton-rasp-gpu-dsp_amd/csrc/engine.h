@@ -166,7 +166,8 @@ class Engine {
 
  private:
   Engine() = default;
-  bool EnsureWork(std::size_t items, std::string *error);
+  // work_[0..3] for `items` channel-blocks; fourth = false (two-level path): no second phase-sized buffer
+  bool EnsureWork(std::size_t items, std::string *error, bool fourth = true);
   void PickChannelGroup(std::size_t blocks);
   bool PlanarizeInput(const Geometry &g, const IoDesc &io, std::size_t blocks, bool splitPlanar, void *stream, IoDesc *ioF,
                       std::string *error);
@@ -200,6 +201,7 @@ class Engine {
   // staged-path work arrays
   cf *work_[4] = {nullptr, nullptr, nullptr, nullptr};
   std::size_t workItems_ = 0;
+  bool workFourth_ = false;  // work_[3] is allocated for workItems_ items
   // host-buffer staging: two device slots per direction
   void *stageIn_[2] = {nullptr, nullptr}, *stageOut_[2] = {nullptr, nullptr};
   std::size_t stageInBytes_ = 0, stageOutBytes_ = 0;

@@ -919,6 +919,7 @@ bool Engine::Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std
       w = nullptr;
     }
     workItems_ = 0;
+    workFourth_ = false;
   }
   filter_ = std::move(filter);
   fused_ = filter_->hasFused() && FusedCovers(g, channels_, inFmt_, outFmt_);
@@ -928,10 +929,11 @@ bool Engine::Rebind(std::shared_ptr<DeviceFilter> filter, bool resetHistory, std
   return true;
 }
 
-bool Engine::EnsureWork(std::size_t items, std::string *error) {
-  if (items <= workItems_) {
+bool Engine::EnsureWork(std::size_t items, std::string *error, bool fourth) {
+  if (items <= workItems_ && (!fourth || workFourth_)) {
     return true;
   }
+  items = std::max(items, workItems_);
   const Geometry &g = filter_->geometry();
   Reap(true);
   for (auto *&w : work_) {
@@ -939,11 +941,15 @@ bool Engine::EnsureWork(std::size_t items, std::string *error) {
     w = nullptr;
   }
   workItems_ = 0;
+  workFourth_ = false;
   const std::size_t row = static_cast<std::size_t>(g.K) * sizeof(cf);
   MI_HIP(hipMalloc(reinterpret_cast<void **>(&work_[0]), items * row));
   MI_HIP(hipMalloc(reinterpret_cast<void **>(&work_[1]), items * row));
   MI_HIP(hipMalloc(reinterpret_cast<void **>(&work_[2]), items * row * g.P));
-  MI_HIP(hipMalloc(reinterpret_cast<void **>(&work_[3]), items * row * g.P));
+  if (fourth) {
+    MI_HIP(hipMalloc(reinterpret_cast<void **>(&work_[3]), items * row * g.P));
+    workFourth_ = true;
+  }
   workItems_ = items;
   return true;
 }
@@ -1350,10 +1356,10 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     lastTwoLevel_ = true;
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
-    const std::size_t perItem = static_cast<std::size_t>(2 + 2 * g.P) * g.K * sizeof(cf);          // EnsureWork's rows
+    const std::size_t perItem = static_cast<std::size_t>(2 + g.P) * g.K * sizeof(cf);              // A, X and the P rows of B
     const std::size_t budget = static_cast<std::size_t>(1024) << 20;
     const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / (perItem * channels_ + perPair)));
-    if (!EnsureWork(chunk * channels_, error)) {
+    if (!EnsureWork(chunk * channels_, error, false)) {
       return false;
     }
     if (chunk * perPair > scratchBytes_) {
