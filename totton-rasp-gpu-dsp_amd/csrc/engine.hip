@@ -1357,7 +1357,10 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
     const std::size_t perItem = static_cast<std::size_t>(2 + g.P) * g.K * sizeof(cf);              // A, X and the P rows of B
-    const std::size_t budget = static_cast<std::size_t>(1024) << 20;
+    std::size_t budget = static_cast<std::size_t>(1024) << 20;
+    if (const char *mb = std::getenv("MIUPS_EXP_TWO_LEVEL_BUDGET_MB")) {  // experiment switch (profiles/r03_q_two_level.txt)
+      budget = static_cast<std::size_t>(std::max(1, std::atoi(mb))) << 20;
+    }
     const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / (perItem * channels_ + perPair)));
     if (!EnsureWork(chunk * channels_, error, false)) {
       return false;
