@@ -465,7 +465,7 @@ int main(int argc, char **argv) {
                           [&]() { tiled_row_inverse_kernel<LOG2M, KK1>(g, spectral, t.tw.data(), Bw.data()); });
         const long long rows = static_cast<long long>(n) * g.P;
         miups_emu::launch(Blocks(rows * M2, 64), 64, 0, false,
-                          [&]() { tiled_store_kernel<KK1>(g, t.tw.data(), Bw.data(), planes.data(), rows); });
+                          [&]() { tiled_store_kernel<KK1>(g, t.tw.data(), Bw.data(), planes.data(), rows, 1); });
       };
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);

@@ -247,14 +247,17 @@ MI_GLOBAL MI_LAUNCH_BOUNDS((TiledRowCfg<LOG2M>::T), 1) void tiled_row_inverse_ke
 // thread = (item * P + p, n2); planes[item - item0][p][i] = y_p[Oc + i]  (the fused path's plane layout)
 template <int K1>
 MI_GLOBAL void tiled_store_kernel(Geometry g, const cf *MI_RESTRICT tw, const cf *MI_RESTRICT B, float *MI_RESTRICT planes,
-                                  long long nrows) {
+                                  long long nrows, int newest_first) {
   const int M2 = g.K / K1;
   const long long gid = static_cast<long long>(MI_BID_X) * MI_BDIM_X + MI_TID_X;
   if (gid >= nrows * M2) {
     return;
   }
-  const long long ip = gid / M2;  // (item, phase)
-  const int n2 = static_cast<int>(gid - ip * M2);
+  // (item, phase) rows are walked NEWEST FIRST: B is larger than the 256 MB Infinity Cache and was written in row order just
+  // before -- its tail may still be cached, its head is not (measured +1..2 % on the whole call: profiles/r03_q_two_level.txt)
+  const long long slot = gid / M2;
+  const int n2 = static_cast<int>(gid - slot * M2);
+  const long long ip = newest_first ? nrows - 1 - slot : slot;
   const cf *src = B + ip * g.K + n2;
   cf v[K1];
   MI_UNROLL

@@ -158,7 +158,9 @@ bool LaunchTiledSized(const Geometry &g, const IoDesc &io, const TableSet &tabs,
   hipLaunchKernelGGL((tiled_row_inverse_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * g.P * K1), dim3(Cfg::T),
                      Cfg::LDS_BYTES, st, g, spectral, tabs.tw, B);
   const long long rows = static_cast<long long>(n) * g.P;
-  hipLaunchKernelGGL((tiled_store_kernel<K1>), dim3(Blocks(rows * M2, threads)), dim3(threads), 0, st, g, tabs.tw, B, planes, rows);
+  const int newestFirst = std::getenv("MIUPS_EXP_TWO_LEVEL_STORE_FORWARD") == nullptr ? 1 : 0;  // experiment switch (profiles/)
+  hipLaunchKernelGGL((tiled_store_kernel<K1>), dim3(Blocks(rows * M2, threads)), dim3(threads), 0, st, g, tabs.tw, B, planes, rows,
+                     newestFirst);
   return HipOk(hipGetLastError(), "two-level transform kernels", error);
 }
 
