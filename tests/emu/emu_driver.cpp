@@ -407,14 +407,15 @@ int main(int argc, char **argv) {
     } else if (tiled) {
       // same sequence as Engine::ProcessDevice's two-level branch, in two chunks of pairs (item0 > 0)
       const int K1 = 1 << tiled_log2k1(g.log2k), M2 = g.K / K1;
-      std::vector<cf> tGs(t.Gs.size()), tGc(t.Gc.size()), tWm(t.Wm.size());
+      std::vector<f4> tGsc(t.Gs.size());  // {Gs, Gc} per bin and phase, as DeviceFilter::StageTables builds them
+      std::vector<cf> tWm(t.Wm.size());
       for (int k1 = 0; k1 < K1; ++k1) {
         for (int k2 = 0; k2 < M2; ++k2) {
           const size_t to = static_cast<size_t>(k1) * M2 + k2, from = static_cast<size_t>(k1) + static_cast<size_t>(K1) * k2;
           tWm[to] = t.Wm[from];
           for (int p = 0; p < g.P; ++p) {
-            tGs[static_cast<size_t>(p) * g.K + to] = t.Gs[static_cast<size_t>(p) * g.K + from];
-            tGc[static_cast<size_t>(p) * g.K + to] = t.Gc[static_cast<size_t>(p) * g.K + from];
+            const cf a = t.Gs[static_cast<size_t>(p) * g.K + from], b = t.Gc[static_cast<size_t>(p) * g.K + from];
+            tGsc[static_cast<size_t>(p) * g.K + to] = f4{a.x, a.y, b.x, b.y};
           }
         }
       }
@@ -457,10 +458,10 @@ int main(int argc, char **argv) {
         using Cfg = TiledRowCfg<LOG2M>;
         miups_emu::launch(Blocks(static_cast<long long>(n) * M2, 64), 64, 0, false,
                           [&]() { tiled_load_kernel<KK1>(g, ioL, t.tw.data(), A.data(), item0, n); });
-        TiledRowSrc plain{A.data(), nullptr, nullptr, nullptr};
+        TiledRowSrc plain{A.data(), nullptr, nullptr};
         miups_emu::launch(static_cast<unsigned>(n) * KK1, Cfg::T, Cfg::LDS_BYTES, true,
                           [&]() { tiled_row_forward_kernel<LOG2M, KK1>(g, plain, t.tw.data(), X.data()); });
-        TiledRowSrc spectral{X.data(), tWm.data(), tGs.data(), tGc.data()};
+        TiledRowSrc spectral{X.data(), tWm.data(), tGsc.data()};
         miups_emu::launch(static_cast<unsigned>(n) * g.P * KK1, Cfg::T, Cfg::LDS_BYTES, true,
                           [&]() { tiled_row_inverse_kernel<LOG2M, KK1>(g, spectral, t.tw.data(), Bw.data()); });
         const long long rows = static_cast<long long>(n) * g.P;

@@ -106,8 +106,8 @@ struct TiledRowCfg {
 struct TiledRowSrc {
   const cf *rows;   // plain: A; spectral: X   (both [item][K1][M2])
   const cf *WmT;    // spectral: [K1][M2]   W_M^k, k = k1 + K1 k2
-  const cf *GsT;    // spectral: [P][K1][M2]
-  const cf *GcT;    // spectral: [P][K1][M2]
+  const f4 *GscT;   // spectral: [P][K1][M2] {Gs, Gc} of the bin as ONE 16-byte word (the L2 -> CU path is bound per load
+                    // instruction, not per byte: scripts/ubench/load_width.hip -- four operand streams instead of five)
 };
 
 template <int LOG2M, int DIR, bool SPECTRAL, int K1>
@@ -122,8 +122,7 @@ struct TiledRow {
     const cf *x;    // plain: the row of A; spectral: the row of X
     const cf *xm;   // spectral: the mirror row of X (read backwards)
     const cf *w;    // spectral: untangle twiddles of the row
-    const cf *gs;   // spectral: the phase's spectrum words of the row
-    const cf *gc;
+    const f4 *gsc;  // spectral: the phase's {Gs, Gc} words of the row
     int k1;
   };
   static MI_DEVICE Rows make_rows(const Geometry &g, const TiledRowSrc &src, long long it, int p, int k1) {
@@ -134,8 +133,7 @@ struct TiledRow {
       const int m1 = (K1 - k1) & (K1 - 1);
       r.xm = src.rows + (it * K1 + m1) * M;
       r.w = src.WmT + static_cast<long long>(k1) * M;
-      r.gs = src.GsT + static_cast<long long>(p) * g.K + static_cast<long long>(k1) * M;
-      r.gc = src.GcT + static_cast<long long>(p) * g.K + static_cast<long long>(k1) * M;
+      r.gsc = src.GscT + static_cast<long long>(p) * g.K + static_cast<long long>(k1) * M;
     }
     return r;
   }
@@ -145,7 +143,8 @@ struct TiledRow {
       return r.x[i];
     } else {
       const int m2 = r.k1 ? M - 1 - i : ((M - i) & (M - 1));
-      return spectral_bin(r.x[i], r.xm[m2], r.w[i], r.gs[i], r.gc[i]);
+      const f4 gg = r.gsc[i];
+      return spectral_bin(r.x[i], r.xm[m2], r.w[i], mk(gg.x, gg.y), mk(gg.z, gg.w));
     }
   }
 

@@ -151,10 +151,10 @@ bool LaunchTiledSized(const Geometry &g, const IoDesc &io, const TableSet &tabs,
   const int threads = 256;
   hipLaunchKernelGGL((tiled_load_kernel<K1>), dim3(Blocks(static_cast<long long>(n) * M2, threads)), dim3(threads), 0, st, g, io,
                      tabs.tw, A, item0, n);
-  TiledRowSrc plain{A, nullptr, nullptr, nullptr};
+  TiledRowSrc plain{A, nullptr, nullptr};
   hipLaunchKernelGGL((tiled_row_forward_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * K1), dim3(Cfg::T), Cfg::LDS_BYTES, st,
                      g, plain, tabs.tw, X);
-  TiledRowSrc spectral{X, tabs.tWm, tabs.tGs, tabs.tGc};
+  TiledRowSrc spectral{X, tabs.tWm, reinterpret_cast<const f4 *>(tabs.tGs)};
   hipLaunchKernelGGL((tiled_row_inverse_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * g.P * K1), dim3(Cfg::T),
                      Cfg::LDS_BYTES, st, g, spectral, tabs.tw, B);
   const long long rows = static_cast<long long>(n) * g.P;
@@ -468,16 +468,15 @@ bool DeviceFilter::StageTables(const std::vector<std::complex<double>> *eqHalf, 
   std::vector<cf> tGs, tGc, tWm;
   if (tiled_covers(t.geo.log2k) && t.Gs.size() == static_cast<std::size_t>(t.geo.P) * t.geo.K) {
     const int K = t.geo.K, K1 = 1 << tiled_log2k1(t.geo.log2k), M2 = K / K1;
-    tGs.resize(t.Gs.size());
-    tGc.resize(t.Gc.size());
+    tGs.resize(2 * t.Gs.size());  // {Gs, Gc} interleaved: one 16-byte word per bin and phase (tGc stays empty)
     tWm.resize(t.Wm.size());
     for (int k1 = 0; k1 < K1; ++k1) {
       for (int k2 = 0; k2 < M2; ++k2) {
         const std::size_t to = static_cast<std::size_t>(k1) * M2 + k2, from = static_cast<std::size_t>(k1) + static_cast<std::size_t>(K1) * k2;
         tWm[to] = t.Wm[from];
         for (int p = 0; p < t.geo.P; ++p) {
-          tGs[static_cast<std::size_t>(p) * K + to] = t.Gs[static_cast<std::size_t>(p) * K + from];
-          tGc[static_cast<std::size_t>(p) * K + to] = t.Gc[static_cast<std::size_t>(p) * K + from];
+          tGs[2 * (static_cast<std::size_t>(p) * K + to)] = t.Gs[static_cast<std::size_t>(p) * K + from];
+          tGs[2 * (static_cast<std::size_t>(p) * K + to) + 1] = t.Gc[static_cast<std::size_t>(p) * K + from];
         }
       }
     }
@@ -1347,7 +1346,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
         }
       }
     }
-  } else if (tiled_covers(g.log2k) && tabs->count[9] == static_cast<std::size_t>(g.P) * g.K &&
+  } else if (tiled_covers(g.log2k) && tabs->count[9] == 2 * static_cast<std::size_t>(g.P) * g.K &&
              static_cast<long long>(blocks) * streams_ * channels_ * g.P * 32 < (1ll << 31) &&
              std::getenv("MIUPS_EXP_NO_TWO_LEVEL") == nullptr) {  // experiment switch (profiles/): the pass-per-launch form
     // K = 2^15 .. 2^18 outside the fused kernels (the "2m" filters at 2x / 4x / 8x): two-level transforms with the
