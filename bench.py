@@ -320,21 +320,38 @@ class Workload:
         self.eng.enable_class_timing(False)
         return {k: round(sum(v) / len(v), 5) for k, v in acc.items()}
 
+    def eq_folded_fir(self, h: np.ndarray) -> np.ndarray:
+        """The EQ folded into the FIR as include/mi_upsampler.h defines it, restated with scipy (nothing from oracle/):
+        the cascade's recursion over the taps in fp64, cut to `taps` samples with a closing half-Hann over the last
+        (taps-1)//64. Biquad coefficients from the library's host helper (pinned to the compiled reference at 1e-14 in
+        tests/test_host_logic.py). The stream is then ONE linear convolution with this FIR: no block-periodic wrap."""
+        from scipy.signal import lfilter
+
+        import totton_rasp_gpu_dsp_amd as ups
+
+        preamp, bands = ups.eq_parse(self.eq_text)
+        y = h * (10.0 ** (preamp / 20.0) if preamp != 0.0 else 1.0)
+        for en, typ, freq, gain, q in bands[:, :5]:  # rows: enabled, type, frequency, gain, q, ...
+            if en:
+                c = ups.eq_biquad(True, int(typ), freq, gain, q, self.eq_fs)
+                y = lfilter(c[:3], [1.0, c[3], c[4]], y)
+        W = (h.size - 1) // 64
+        if W:
+            y[h.size - W:] *= 0.5 * (1.0 + np.cos(np.pi * (np.arange(W) + 0.5) / W))
+        return y
+
     def truth_block(self, stream_slot: int, channel: int, blk: int, x_stream: np.ndarray) -> np.ndarray:
         """fp64 statement of one output block of one channel (numpy only, nothing from oracle/): the reference's
-        N-point overlap-save, Y = FFT_N([history | zero-stuffed input]) * FFT_N(h) * EQ, y = Re IFFT_N(Y), keep the
-        last B (vulkan_streaming_upsampler.cpp:528-569). `x_stream` = this stream's PCM frames as float [frames][ch].
+        N-point overlap-save, Y = FFT_N([history | zero-stuffed input]) * FFT_N(h), y = Re IFFT_N(Y), keep the
+        last B; with an EQ, h is the EQ-folded FIR of the same length (eq_folded_fir), so this equals the true streaming
+        convolution (vulkan_streaming_upsampler.cpp:528-569). `x_stream` = this stream's PCM frames as float [frames][ch].
         The history of block `blk` is the O/L frames before it (the engine carries it; blocks >= 2 lie inside the call)."""
         n, B, L = self.cfg["fft_size"], self.cfg["block_size"], self.cfg["upsample_factor"]
         O, nin = n - B, B // L
         h = np.fromfile(self.cfg["coefficients_path"], "<f4").astype(np.float64)
-        H = np.fft.rfft(np.concatenate([h, np.zeros(n - h.size)]))
         if self.use_eq:
-            import totton_rasp_gpu_dsp_amd as ups
-
-            eq = ups.eq_response_host(self.eq_text, n // 2 + 1, n, self.eq_fs)
-            eq[0], eq[-1] = eq[0].real, eq[-1].real
-            H = H * eq
+            h = self.eq_folded_fir(h)
+        H = np.fft.rfft(np.concatenate([h, np.zeros(n - h.size)]))
         t = np.zeros(n)
         first = blk * nin - O // L
         assert first >= 0, "probe block must lie far enough inside the call"

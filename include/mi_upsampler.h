@@ -99,10 +99,32 @@ int mi_ups_get_config(const mi_ups *h, mi_ups_config *out);
  * (mi_ups_last_error() tells which). out must hold block_size floats. */
 long mi_ups_process_block(mi_ups *h, const float *input, size_t count, float *out, size_t outcap);
 int mi_ups_reset(mi_ups *h);
-/* optional EQ (reference: eq_parser.cpp / eq_to_fir.cpp, no call site there):
- * fold the APO profile's complex response, sampled at k*fs_out/fft_size, into
- * the filter spectrum. Empty/NULL text removes the EQ. */
+/* optional EQ (reference: eq_parser.cpp / eq_to_fir.cpp, no call site there). The APO profile's biquad cascade is folded
+ * into the FIR itself: its recursion runs over the filter taps in fp64 and the result is cut back to `taps` samples
+ * (closing half-Hann over the last (taps-1)/64), so the product is still ONE linear convolution with at most `taps`
+ * samples, fft_size - block_size == taps - 1 still holds and nothing wraps around inside a block. What the
+ * cut drops is measured (mi_eq_residual). Above the limit (default 1e-3 = -60 dB, mi_*_set_eq_limit) the call still
+ * succeeds and mi_ups_last_error() holds a warning that says by how much; a handle made strict refuses instead
+ * (MI_ERR_FILTER, the previous spectrum stays). Empty/NULL text removes the EQ. */
 int mi_ups_set_eq(mi_ups *h, const char *apo_text, double fs_out);
+/* What the latest successful EQ change dropped. h_ideal = taps (*) cascade is infinitely long, the filter uses
+ * fir[n] = w[n] h_ideal[n], n < taps:
+ *   tail_l1 = ||h_ideal - fir||_1 / ||h_ideal||_1   output error <= tail_l1 * ||h_ideal||_1 * max|x| for ANY input
+ *   tail_l2 = the same in the 2-norm (error power for white input);   *_db = 20 log10 (-400 for 0)
+ *   response_dev = max_k |FFT_N(fir)[k] - H_fir[k] EQ(f_k)| / max_k |H_fir EQ|, EQ(f_k) = the cascade evaluated per bin on
+ *                  the device as computeEqResponseForFft does (eq_to_fir.cpp:145-151)
+ *   tail_complete = 0: the free decay had not died after 2e8 section-steps; its rest is estimated from the pole radius */
+typedef struct mi_eq_residual {
+  int active;        /* 0: no EQ folded in (everything else 0) */
+  int over_limit;    /* tail_l1 > limit */
+  int tail_complete;
+  int reserved;
+  double tail_l1, tail_l2, tail_l1_db, tail_l2_db, response_dev, response_dev_db, limit;
+  size_t fir_taps, taper;
+} mi_eq_residual;
+int mi_ups_eq_residual(const mi_ups *h, mi_eq_residual *out);
+/* max_tail_l1 < 0: the default (1e-3); strict != 0: an EQ over the limit is refused */
+int mi_ups_set_eq_limit(mi_ups *h, double max_tail_l1, int strict);
 
 /* ------------------------------------------------------------------ (2) --
  * Shared device-resident filter + batched multi-channel engine.
@@ -116,6 +138,8 @@ int mi_filter_from_taps(int device, const float *taps, size_t n_taps, size_t fft
                         size_t upsample_factor, int flags, mi_filter **out, char *err, size_t errcap);
 int mi_filter_get_config(const mi_filter *f, mi_ups_config *out);
 int mi_filter_set_eq(mi_filter *f, const char *apo_text, double fs_out);
+int mi_filter_eq_residual(const mi_filter *f, mi_eq_residual *out);
+int mi_filter_set_eq_limit(mi_filter *f, double max_tail_l1, int strict);
 /* Evaluate the EQ cascade on the device (fp64): num_bins (re,im) pairs at
  * f_i = i*fs_out/full_fft -- computeEqResponseForFft, eq_to_fir.cpp:145-151 */
 int mi_eq_response_device(int device, const char *apo_text, size_t num_bins, size_t full_fft, double fs_out,
@@ -235,6 +259,8 @@ int mi_multi_create(const char *json_path, int flags, const int *devices, size_t
                     int in_fmt, int out_fmt, mi_multi **out, char *err, size_t errcap);
 void mi_multi_destroy(mi_multi *m);
 int mi_multi_set_eq(mi_multi *m, const char *apo_text, double fs_out);
+int mi_multi_eq_residual(const mi_multi *m, mi_eq_residual *out);
+int mi_multi_set_eq_limit(mi_multi *m, double max_tail_l1, int strict);
 int mi_multi_reset(mi_multi *m);
 /* all streams, HOST buffers, stream s at base + s*stride; returns when every device has finished */
 int mi_multi_process_host(mi_multi *m, const void *h_in, size_t in_stream_stride_bytes, void *h_out,
@@ -299,6 +325,10 @@ int mi_eq_biquad(int enabled, int type, double freq, double gain, double q, doub
 /* computeEqResponseForFft / computeEqMagnitudeForFft, host fp64 */
 int mi_eq_response_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_reim);
 int mi_eq_magnitude_host(const char *text, size_t num_bins, size_t full_fft, double fs_out, double *out_mag);
+/* The EQ-folded FIR itself, host only (what mi_*_set_eq hands to the table build): out_fir gets n_taps doubles (may be
+ * NULL), *out the residual (response_dev against the host evaluation of the cascade; limit = the default). */
+int mi_eq_fold_host(const float *taps, size_t n_taps, size_t fft_size, const char *apo_text, double fs_out, double *out_fir,
+                    mi_eq_residual *out);
 
 /* Rate-family detection and output-rate negotiation (src/audio/auto_negotiation.cpp:13-155). The DAC is given as the
  * reference's capability probe reports it: valid flag, min/max rate, optional list of discrete rates. */

@@ -15,7 +15,10 @@ Three checkers live here (citations relative to /root/reference):
 * numpy restatements of the byte/float work that cannot be compiled here
   (ALSA headers are absent): PCM<->float (``src/alsa/alsa_common.cpp:42-127``),
   the EQ maths (``src/audio/eq_to_fir.cpp``), the APO parser
-  (``src/audio/eq_parser.cpp:177-259``) and an fp64 "truth" convolution.
+  (``src/audio/eq_parser.cpp:177-259``), an fp64 "truth" convolution, and the
+  EQ folded into the FIR (``eq_fold_fir``: this repo's own definition -- the
+  reference never calls its EQ code from the data plane, so that fusion is
+  "parity unpinned"; its pieces, the biquads and the per-bin response, are pinned).
 """
 from __future__ import annotations
 
@@ -453,27 +456,59 @@ def hermitian_extend(half: np.ndarray, n: int) -> np.ndarray:
     return full
 
 
-def eq_fused_stream_truth(x, h, factor, fft, block, nblocks, eq_half) -> np.ndarray:
-    """fp64 statement of THIS repo's EQ fusion (the reference has no call site,
-    SURVEY §8 hard part D -- parity of the fusion itself is UNPINNED): per block,
-    Y = FFT_N(timeBuffer) * FFT_N(h) * EQ  on all N bins (EQ Hermitian-extended,
-    Nyquist bin real part only), y = Re IFFT_N(Y), keep the last `block`."""
-    n = fft
-    ov = n - block
-    H = np.fft.fft(np.concatenate([np.asarray(h, np.float64), np.zeros(n - len(h))]))
-    half = np.array(eq_half, dtype=np.complex128).copy()
-    half[0] = half[0].real
-    half[n // 2] = half[n // 2].real
-    Ht = H * hermitian_extend(half, n)
-    x = np.asarray(x, np.float64)
-    nin = block // factor
-    overlap = np.zeros(ov)
-    out = np.empty((nblocks, block))
-    for b in range(nblocks):
-        t = np.zeros(n)
-        t[:ov] = overlap
-        t[ov::factor][:nin] = x[b * nin : (b + 1) * nin]
-        y = np.fft.ifft(np.fft.fft(t) * Ht).real
-        out[b] = y[ov:]
-        overlap = t[n - ov :].copy()
-    return out
+def eq_sections(text: str, fs_out: float):
+    """(preamp_linear, [b0,b1,b2,a1,a2] of every enabled, non-bypass band): the cascade of eq_to_fir.cpp:102-130."""
+    _, preamp, bands = eq_parse(text)
+    secs = []
+    for b in bands:
+        if b["enabled"]:
+            c = eq_biquad(b, fs_out)
+            if not (c[0] == 1.0 and not c[1:].any()):
+                secs.append(c)
+    return (10.0 ** (preamp / 20.0) if preamp != 0.0 else 1.0), secs
+
+
+def eq_cascade_filter(text: str, fs_out: float, x: np.ndarray) -> np.ndarray:
+    """The cascade run as the recursion it is, fp64 (scipy.signal.lfilter per section), over any sequence."""
+    from scipy.signal import lfilter
+
+    g, secs = eq_sections(text, fs_out)
+    y = np.asarray(x, dtype=np.float64) * g
+    for c in secs:
+        y = lfilter(c[:3], [1.0, c[3], c[4]], y)
+    return y
+
+
+def eq_fold_taper(taps: int) -> np.ndarray:
+    """Closing half-Hann over the last W = (taps-1)//64 samples (this repo's definition, csrc/host/eq.h)."""
+    w = np.ones(taps)
+    W = (taps - 1) // 64
+    if W:
+        w[taps - W:] = 0.5 * (1.0 + np.cos(np.pi * (np.arange(W) + 0.5) / W))
+    return w
+
+
+def eq_fold_fir(h: np.ndarray, text: str, fs_out: float) -> np.ndarray:
+    """fp64 statement of THIS repo's EQ fusion (the reference has no call site, SURVEY 7 hard part D -- parity of the
+    fusion itself is UNPINNED; the per-bin EQ maths and the biquad coefficients are pinned): the EQ becomes part of the
+    FIR, fir[n] = w[n] * (h (*) h_cascade)[n] for n < taps. The stream is then a plain linear convolution with `fir`
+    (truth_stream); what the cut drops against the ideal, infinitely long response is eq_fold_residual."""
+    h = np.asarray(h, dtype=np.float64)
+    return eq_cascade_filter(text, fs_out, h) * eq_fold_taper(h.size)
+
+
+def eq_fold_residual(h: np.ndarray, text: str, fs_out: float, extend: int) -> dict:
+    """||h_ideal - fir||_p / ||h_ideal||_p with the ideal response followed for `extend` samples past the taps."""
+    h = np.asarray(h, dtype=np.float64)
+    ideal = eq_cascade_filter(text, fs_out, np.concatenate([h, np.zeros(extend)]))
+    d = ideal.copy()
+    d[: h.size] -= ideal[: h.size] * eq_fold_taper(h.size)
+    return dict(tail_l1=np.abs(d).sum() / np.abs(ideal).sum(), tail_l2=math.sqrt((d * d).sum() / (ideal * ideal).sum()),
+                l1_ideal=np.abs(ideal).sum(), end=np.abs(ideal[-4096:]).sum() / np.abs(ideal).sum())
+
+
+def eq_ideal_stream(x: np.ndarray, h: np.ndarray, factor: int, text: str, fs_out: float, nblocks: int, block: int):
+    """What an upsampler followed by the REAL (recursive, infinitely long) cascade produces: the yardstick the folded
+    FIR's stream is held against, with the stated residual as the allowance."""
+    y = truth_stream(x, h, factor, nblocks, block).reshape(-1)
+    return eq_cascade_filter(text, fs_out, y).reshape(nblocks, block)

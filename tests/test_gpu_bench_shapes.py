@@ -56,8 +56,7 @@ def truth_channel(O, ups, w, slot, ch) -> np.ndarray:
     h, taps, fft, block, L = O.read_filter(w.fpath)
     x = w.host_pcm[slot][:, ch].astype(np.float64) / 2147483648.0
     if w.use_eq:
-        eq_half = O.eq_response(w.eq_text, fft // 2 + 1, fft, w.eq_fs)
-        y = O.eq_fused_stream_truth(x, h, L, fft, block, w.blocks, eq_half).reshape(-1)
+        y = O.truth_stream(x, O.eq_fold_fir(h, w.eq_text, w.eq_fs), L, w.blocks, block).reshape(-1)
     else:
         y = O.truth_stream(x, h, L, w.blocks, block).reshape(-1)
     return np.clip(y, -1.0, F32_HI)

@@ -43,15 +43,16 @@ def test_empty_eq_profile_is_unity(ups, gpu):
                                       ("filter_44k_4x_80000_min_phase.json", 705600.0),
                                       ("filter_44k_2x_80000_min_phase.json", 705600.0)])  # K = 32768: split kernel tables
 def test_eq_folded_into_filter_spectrum(ups, O, gpu, fname, fs):
-    """H_total[k] = H_fir[k] * EQ(k fs/N) on all N bins (this repo's definition of
-    the fusion; the reference has no call site, so only the per-bin EQ values are
-    pinned to it). Checked against an fp64 statement of exactly that, 1e-5*max|y|."""
+    """The EQ is folded into the FIR (cascade recursion over the taps, cut to `taps` samples: this repo's definition of
+    the fusion; the reference has no call site, so only the biquads and the per-bin EQ values are pinned to it). The
+    stream is then ONE linear convolution: checked against the fp64 true streaming convolution with the folded FIR,
+    1e-5*max|y| -- a truth with no block structure in it, so a wrap inside a block would show."""
     path = ROOT / "data" / "coefficients" / fname
     h, taps, fft, block, L = O.read_filter(path)
     text = PROFILES["opra10"]
     nin, nb = block // L, 3
     x = real_input(21, nb * nin)
-    want = O.eq_fused_stream_truth(x, h, L, fft, block, nb, O.eq_response(text, fft // 2 + 1, fft, fs))
+    want = O.truth_stream(x, O.eq_fold_fir(h, text, fs), L, nb, block)
     u = ups.StreamingUpsampler(gpu)
     assert u.load_filter(path)[0]
     plain = np.stack([u.process_block(x[b * nin:(b + 1) * nin]) for b in range(nb)])
@@ -76,8 +77,7 @@ def test_eq_folded_into_filter_spectrum(ups, O, gpu, fname, fs):
 def test_bench_configs_with_eq_as_benched(ups, O, gpu, fname, fs, channels, blocks):
     """bench.py --config 3 / --config 5 exactly as timed: mi_filter_set_eq(opra10) on the shared filter, then the
     batched engine on interleaved s32 frames of `channels` channels (planarize -> fused -> interleave kernels).
-    Checked per channel against the fp64 statement of the fusion on the filter's own N-point grid (for config 5
-    that is the 131 073-bin grid of N = 262144): 1 LSB + 1e-5 * max|y|."""
+    Checked per channel against the fp64 true streaming convolution with the EQ-folded FIR: 1 LSB + 1e-5 * max|y|."""
     path = ROOT / "data" / "coefficients" / fname
     h, taps, fft, block, L = O.read_filter(path)
     text = PROFILES["opra10"]
@@ -90,9 +90,9 @@ def test_bench_configs_with_eq_as_benched(ups, O, gpu, fname, fs, channels, bloc
     raw = O.float_to_pcm(xf.reshape(-1), "s32")
     xin = O.pcm_to_float(raw, "s32").reshape(blocks * nin, channels)
     y = O.pcm_to_float(eng.process_host(raw, blocks), "s32").reshape(blocks * block, channels)
-    eq_half = O.eq_response(text, fft // 2 + 1, fft, fs)
+    fir = O.eq_fold_fir(h, text, fs)
     for c in sorted({0, 1, channels // 2, channels - 1}):
-        want = O.eq_fused_stream_truth(xin[:, c], h, L, fft, block, blocks, eq_half).reshape(-1)
+        want = O.truth_stream(xin[:, c], fir, L, blocks, block).reshape(-1)
         assert np.abs(want).max() < 0.9          # nothing clamps: the comparison is of the filter, not of the limiter
         assert np.abs(y[:, c] - want).max() <= 2.0**-31 + 1e-5 * np.abs(want).max()
 

@@ -590,8 +590,8 @@ def test_640k_tap_filters_take_the_two_level_path(ups, O, gpu, tmp_path, monkeyp
 
 def test_two_level_path_with_eq_folded_in(ups, O, gpu, tmp_path):
     """mi_filter_set_eq on a 640k-tap filter: the two-level path's own copies of the spectrum tables ([k1][k2] order) are
-    rebuilt with the EQ response folded in. 8x, two channels, two calls, against the fp64 statement of H_fir * EQ on the
-    N-point grid (the same truth the fused path's EQ tests use); and back to the plain filter afterwards."""
+    rebuilt with the EQ folded into the FIR. 8x, two channels, two calls, against the fp64 true streaming convolution with
+    the folded FIR (the same truth the fused path's EQ tests use); and back to the plain filter afterwards."""
     import json
 
     sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
@@ -612,9 +612,10 @@ def test_two_level_path_with_eq_folded_in(ups, O, gpu, tmp_path):
     y = np.concatenate([eng.process_host(x[k * blocks * nin:(k + 1) * blocks * nin], blocks).view(np.float32)
                         .reshape(blocks * block, channels) for k in range(2)])
     assert eng.path == "staged" and eng.last_two_level
-    eq_half = O.eq_response(eq_text, fft // 2 + 1, fft, fs_out)
+    fir = O.eq_fold_fir(h32, eq_text, fs_out)
+    assert filt.eq_residual()["over_limit"] == 0
     for c in range(channels):
-        truth = O.eq_fused_stream_truth(x[:, c].astype(np.float64), h32, L, fft, block, 2 * blocks, eq_half).reshape(-1)
+        truth = O.truth_stream(x[:, c].astype(np.float64), fir, L, 2 * blocks, block).reshape(-1)
         assert rel_err(y[:, c], truth) <= TOL_TRUTH
     filt.set_eq("", fs_out)  # plain again: the next call takes the new tables (history restarted for a clean comparison)
     eng.reset()

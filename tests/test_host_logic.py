@@ -229,17 +229,12 @@ def test_eq_types_and_biquads_vs_oracle(ups, O):
 
 
 # ---- load-time tables (spectrum.cpp) vs a numpy statement of the same maths ------
-def numpy_tables(h, fft, block, L, eq_half=None):
+def numpy_tables(h, fft, block, L):
     N = fft
     P = L if N % L == 0 else 1
     M, K = N // P, N // P // 2
     ht = np.zeros(N)
     ht[: len(h)] = h
-    if eq_half is not None:
-        half = np.array(eq_half, dtype=np.complex128)
-        half[0], half[N // 2] = half[0].real, half[N // 2].real
-        full = np.concatenate([half, np.conj(half[1:N // 2][::-1])])
-        ht = np.fft.ifft(np.fft.fft(ht) * full).real
     Gs = np.empty((P, K), np.complex128)
     Gc = np.empty((P, K), np.complex128)
     for p in range(P):
@@ -276,7 +271,7 @@ def test_tables_real_filter_with_eq_and_compat(ups, O):
     h, taps, fft, block, L = O.read_filter(path)
     text = PROFILES["opra10"]
     t = ups.build_tables(path, apo_text=text, fs_out=768000.0)
-    want = numpy_tables(h, fft, block, L, O.eq_response(text, fft // 2 + 1, fft, 768000.0))
+    want = numpy_tables(O.eq_fold_fir(h, text, 768000.0), fft, block, L)  # the EQ is part of the FIR: same length
     scale = np.abs(want["Gs"]).max()
     assert np.abs(t["Gs"] - want["Gs"]).max() <= 2e-7 * scale
     assert np.abs(t["Gc"] - want["Gc"]).max() <= 2e-7 * scale

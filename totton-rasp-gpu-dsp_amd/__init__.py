@@ -69,6 +69,17 @@ BETWEEN_FN = C.CFUNCTYPE(None, C.c_void_p)
 LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 
 
+class _EqResidual(C.Structure):
+    _fields_ = [("active", C.c_int), ("over_limit", C.c_int), ("tail_complete", C.c_int), ("reserved", C.c_int),
+                ("tail_l1", C.c_double), ("tail_l2", C.c_double), ("tail_l1_db", C.c_double), ("tail_l2_db", C.c_double),
+                ("response_dev", C.c_double), ("response_dev_db", C.c_double), ("limit", C.c_double),
+                ("fir_taps", C.c_size_t), ("taper", C.c_size_t)]
+
+
+def _residual(r: "_EqResidual") -> dict:
+    return {n: (getattr(r, n) if t in (C.c_double,) else int(getattr(r, n))) for n, t in r._fields_ if n != "reserved"}
+
+
 class _Config(C.Structure):
     _fields_ = [("taps", C.c_size_t), ("fft_size", C.c_size_t), ("block_size", C.c_size_t),
                 ("upsample_factor", C.c_size_t), ("coefficients_path", C.c_char * 1024)]
@@ -94,6 +105,13 @@ def _load():
         "mi_ups_process_block": (C.c_long, [vp, f32p, sz, f32p, sz]),
         "mi_ups_reset": (i32, [vp]),
         "mi_ups_set_eq": (i32, [vp, cp, dbl]),
+        "mi_ups_eq_residual": (i32, [vp, C.POINTER(_EqResidual)]),
+        "mi_ups_set_eq_limit": (i32, [vp, dbl, i32]),
+        "mi_filter_eq_residual": (i32, [vp, C.POINTER(_EqResidual)]),
+        "mi_filter_set_eq_limit": (i32, [vp, dbl, i32]),
+        "mi_multi_eq_residual": (i32, [vp, C.POINTER(_EqResidual)]),
+        "mi_multi_set_eq_limit": (i32, [vp, dbl, i32]),
+        "mi_eq_fold_host": (i32, [C.POINTER(C.c_float), sz, sz, cp, dbl, f64p, C.POINTER(_EqResidual)]),
         "mi_filter_load": (i32, [i32, cp, i32, C.POINTER(vp), cp, sz]),
         "mi_filter_from_taps": (i32, [i32, f32p, sz, sz, sz, sz, i32, C.POINTER(vp), cp, sz]),
         "mi_filter_get_config": (i32, [vp, C.POINTER(_Config)]),
@@ -212,7 +230,8 @@ EXPORTED_SYMBOLS = [
     "mi_eq_parse", "mi_eq_parse_filter_type", "mi_eq_filter_type_name", "mi_eq_biquad", "mi_eq_response_host",
     "mi_eq_magnitude_host", "mi_tables_build", "mi_tables_geometry", "mi_tables_size", "mi_tables_copy",
     "mi_tables_free", "mi_tables_block_b", "mi_lds_swizzle", "mi_fused_set_of_block", "mi_fused_block_a",
-    "mi_fused_plan_radices",
+    "mi_fused_plan_radices", "mi_ups_eq_residual", "mi_ups_set_eq_limit", "mi_filter_eq_residual",
+    "mi_filter_set_eq_limit", "mi_multi_eq_residual", "mi_multi_set_eq_limit", "mi_eq_fold_host",
 ]
 
 
@@ -275,8 +294,20 @@ class StreamingUpsampler:
         if lib.mi_ups_reset(self._h) != MI_OK:
             raise UpsamplerError(last_error())
 
-    def set_eq(self, apo_text: str, fs_out: float) -> None:
+    def set_eq(self, apo_text: str, fs_out: float) -> str:
+        """Returns the warning text ("" when the EQ fold stayed within the limit)."""
         if lib.mi_ups_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return last_error()
+
+    def eq_residual(self) -> dict:
+        r = _EqResidual()
+        if lib.mi_ups_eq_residual(self._h, C.byref(r)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return _residual(r)
+
+    def set_eq_limit(self, max_tail_l1: float = -1.0, strict: bool = False) -> None:
+        if lib.mi_ups_set_eq_limit(self._h, float(max_tail_l1), int(strict)) != MI_OK:
             raise UpsamplerError(last_error())
 
     def clone(self) -> "StreamingUpsampler":
@@ -318,10 +349,22 @@ class Filter:
         lib.mi_filter_get_config(self._h, C.byref(c))
         return _cfg(c)
 
-    def set_eq(self, apo_text: str, fs_out: float) -> None:
+    def set_eq(self, apo_text: str, fs_out: float) -> str:
         """Glitch-free: engines already running keep the old spectrum for the calls they have enqueued and use the
         new one from their next call on; on failure the old spectrum stays (include/mi_upsampler.h)."""
         if lib.mi_filter_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return last_error()  # "" or the over-the-limit warning
+
+    def eq_residual(self) -> dict:
+        """What folding the EQ into the FIR dropped (include/mi_upsampler.h mi_eq_residual)."""
+        r = _EqResidual()
+        if lib.mi_filter_eq_residual(self._h, C.byref(r)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return _residual(r)
+
+    def set_eq_limit(self, max_tail_l1: float = -1.0, strict: bool = False) -> None:
+        if lib.mi_filter_set_eq_limit(self._h, float(max_tail_l1), int(strict)) != MI_OK:
             raise UpsamplerError(last_error())
 
     @property
@@ -488,8 +531,19 @@ class MultiEngine:
             raise UpsamplerError("mi_multi_worker_cpus")
         return out.value.decode()
 
-    def set_eq(self, apo_text: str, fs_out: float) -> None:
+    def set_eq(self, apo_text: str, fs_out: float) -> str:
         if lib.mi_multi_set_eq(self._h, (apo_text or "").encode(), float(fs_out)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return last_error()
+
+    def eq_residual(self) -> dict:
+        r = _EqResidual()
+        if lib.mi_multi_eq_residual(self._h, C.byref(r)) != MI_OK:
+            raise UpsamplerError(last_error())
+        return _residual(r)
+
+    def set_eq_limit(self, max_tail_l1: float = -1.0, strict: bool = False) -> None:
+        if lib.mi_multi_set_eq_limit(self._h, float(max_tail_l1), int(strict)) != MI_OK:
             raise UpsamplerError(last_error())
 
     def reset(self) -> None:
@@ -778,6 +832,16 @@ def eq_magnitude_host(text: str, num_bins: int, full_fft: int, fs_out: float) ->
     out = np.empty(num_bins)
     lib.mi_eq_magnitude_host(text.encode(), num_bins, full_fft, fs_out, _f64(out))
     return out
+
+
+def eq_fold_host(taps, fft_size: int, text: str, fs_out: float):
+    """(fir float64[taps], residual dict): the EQ-folded FIR the table build receives (host only, no device)."""
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    fir = np.empty(t.size, dtype=np.float64)
+    r = _EqResidual()
+    if lib.mi_eq_fold_host(_f32(t), t.size, int(fft_size), text.encode(), float(fs_out), _f64(fir), C.byref(r)) != MI_OK:
+        raise UpsamplerError("mi_eq_fold_host failed")
+    return fir, _residual(r)
 
 
 def eq_response_device(text: str, num_bins: int, full_fft: int, fs_out: float, device: int = 0) -> np.ndarray:

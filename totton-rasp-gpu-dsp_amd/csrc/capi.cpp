@@ -7,6 +7,7 @@
 #include <signal.h>
 #include <unistd.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -68,6 +69,31 @@ void FillConfig(const FilterConfig &c, mi_ups_config *out) {
   out->upsample_factor = c.upsampleFactor;
   CopyMessage(c.coefficientsPath, out->coefficients_path, sizeof(out->coefficients_path));
 }
+
+void FillResidual(const miups::EqReport &r, mi_eq_residual *out) {
+  auto db = [](double v) { return v > 0.0 ? 20.0 * std::log10(v) : -400.0; };
+  std::memset(out, 0, sizeof(*out));
+  out->active = r.active ? 1 : 0;
+  out->over_limit = r.overLimit ? 1 : 0;
+  out->tail_complete = r.tailComplete ? 1 : 0;
+  out->tail_l1 = r.tailL1;
+  out->tail_l2 = r.tailL2;
+  out->tail_l1_db = db(r.tailL1);
+  out->tail_l2_db = db(r.tailL2);
+  out->response_dev = r.responseDev;
+  out->response_dev_db = db(r.responseDev);
+  out->limit = r.limit;
+  out->fir_taps = r.firTaps;
+  out->taper = r.taper;
+}
+
+// an EQ change that went through but dropped more than the limit: success, with the warning where errors go
+int OkWithEqWarning(const miups::EqReport &r) {
+  miups::SetLastError(miups::EqReportWarning(r));
+  return MI_OK;
+}
+
+int EqFailCode(const std::string &error) { return error.rfind("EQ cut to", 0) == 0 ? MI_ERR_FILTER : MI_ERR_DEVICE; }
 
 template <typename F>
 auto Guard(F &&f, decltype(f()) onThrow) -> decltype(f()) {
@@ -232,20 +258,36 @@ int mi_ups_set_eq(mi_ups *h, const char *apo_text, double fs_out) {
         if (h->filter.use_count() > 2) {
           auto own = h->filter->Fork(apo_text ? apo_text : "", fs_out, &error);
           if (!own) {
-            return Fail(MI_ERR_DEVICE, error);
+            return Fail(EqFailCode(error), error);
           }
           if (!h->engine->Rebind(own, false, &error)) {
             return Fail(MI_ERR_DEVICE, error);
           }
           h->filter = own;
-          return MI_OK;
+          return OkWithEqWarning(h->filter->eqReport());
         }
         if (!h->filter->SetEq(apo_text ? apo_text : "", fs_out, &error)) {
-          return Fail(MI_ERR_DEVICE, error);
+          return Fail(EqFailCode(error), error);
         }
-        return MI_OK;
+        return OkWithEqWarning(h->filter->eqReport());
       },
       MI_ERR_DEVICE);
+}
+
+int mi_ups_eq_residual(const mi_ups *h, mi_eq_residual *out) {
+  if (!h || !h->initialized || !out) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  FillResidual(h->filter->eqReport(), out);
+  return MI_OK;
+}
+
+int mi_ups_set_eq_limit(mi_ups *h, double max_tail_l1, int strict) {
+  if (!h || !h->initialized) {
+    return Fail(MI_ERR_ARG, "not initialised");
+  }
+  h->filter->SetEqLimit(max_tail_l1, strict != 0);
+  return MI_OK;
 }
 
 // ---------------------------------------------------------------- level 2 --
@@ -328,9 +370,28 @@ int mi_filter_set_eq(mi_filter *f, const char *apo_text, double fs_out) {
           return Fail(MI_ERR_ARG, "null filter");
         }
         std::string error;
-        return f->filter->SetEq(apo_text ? apo_text : "", fs_out, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+        if (!f->filter->SetEq(apo_text ? apo_text : "", fs_out, &error)) {
+          return Fail(EqFailCode(error), error);
+        }
+        return OkWithEqWarning(f->filter->eqReport());
       },
       MI_ERR_DEVICE);
+}
+
+int mi_filter_eq_residual(const mi_filter *f, mi_eq_residual *out) {
+  if (!f || !out) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  FillResidual(f->filter->eqReport(), out);
+  return MI_OK;
+}
+
+int mi_filter_set_eq_limit(mi_filter *f, double max_tail_l1, int strict) {
+  if (!f) {
+    return Fail(MI_ERR_ARG, "null filter");
+  }
+  f->filter->SetEqLimit(max_tail_l1, strict != 0);
+  return MI_OK;
 }
 
 int mi_eq_response_device(int device, const char *apo_text, size_t num_bins, size_t full_fft, double fs_out,
@@ -610,9 +671,28 @@ int mi_multi_set_eq(mi_multi *m, const char *apo_text, double fs_out) {
           return Fail(MI_ERR_ARG, "null handle");
         }
         std::string error;
-        return m->multi->SetEq(apo_text ? apo_text : "", fs_out, &error) ? MI_OK : Fail(MI_ERR_DEVICE, error);
+        if (!m->multi->SetEq(apo_text ? apo_text : "", fs_out, &error)) {
+          return Fail(error.find("EQ cut to") != std::string::npos ? MI_ERR_FILTER : MI_ERR_DEVICE, error);
+        }
+        return OkWithEqWarning(m->multi->eqReport());
       },
       MI_ERR_DEVICE);
+}
+
+int mi_multi_eq_residual(const mi_multi *m, mi_eq_residual *out) {
+  if (!m || !out) {
+    return Fail(MI_ERR_ARG, "null argument");
+  }
+  FillResidual(m->multi->eqReport(), out);
+  return MI_OK;
+}
+
+int mi_multi_set_eq_limit(mi_multi *m, double max_tail_l1, int strict) {
+  if (!m) {
+    return Fail(MI_ERR_ARG, "null handle");
+  }
+  m->multi->SetEqLimit(max_tail_l1, strict != 0);
+  return MI_OK;
 }
 
 int mi_multi_reset(mi_multi *m) {

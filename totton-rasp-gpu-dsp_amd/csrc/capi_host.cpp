@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -207,6 +208,45 @@ int mi_eq_magnitude_host(const char *text, size_t num_bins, size_t full_fft, dou
   return MI_OK;
 }
 
+int mi_eq_fold_host(const float *taps, size_t n_taps, size_t fft_size, const char *apo_text, double fs_out, double *out_fir,
+                    mi_eq_residual *out) {
+  if (!taps || !apo_text || n_taps == 0 || !(fs_out > 0.0)) {
+    return MI_ERR_ARG;
+  }
+  try {
+    const std::vector<float> h(taps, taps + n_taps);
+    miups::eq::EqProfile profile;
+    miups::eq::parseEqString(apo_text, profile);
+    miups::eq::EqFold fold = miups::eq::FoldCascadeIntoTaps(h, miups::eq::buildCascade(profile, fs_out));
+    if (out_fir) {
+      std::memcpy(out_fir, fold.fir.data(), n_taps * sizeof(double));
+    }
+    if (out) {
+      auto db = [](double v) { return v > 0.0 ? 20.0 * std::log10(v) : -400.0; };
+      std::memset(out, 0, sizeof(*out));
+      if (fft_size >= n_taps && fft_size >= 2 && (fft_size & (fft_size - 1)) == 0) {
+        fold.responseDev = miups::eq::ResponseDeviation(
+            h, fold.fir, miups::eq::ComputeEqResponseHost(fft_size / 2 + 1, fft_size, fs_out, profile), fft_size);
+      }
+      out->active = 1;
+      out->limit = miups::eq::kFoldDefaultLimit;
+      out->over_limit = fold.tailL1 > out->limit;
+      out->tail_complete = fold.tailComplete ? 1 : 0;
+      out->tail_l1 = fold.tailL1;
+      out->tail_l2 = fold.tailL2;
+      out->tail_l1_db = db(fold.tailL1);
+      out->tail_l2_db = db(fold.tailL2);
+      out->response_dev = fold.responseDev;
+      out->response_dev_db = db(fold.responseDev);
+      out->fir_taps = n_taps;
+      out->taper = fold.taper;
+    }
+  } catch (...) {
+    return MI_ERR_ARG;
+  }
+  return MI_OK;
+}
+
 int mi_tables_build(const char *json_path, int flags, const char *apo_text, double fs_out, mi_tables **out, char *err,
                     size_t errcap) {
   if (!json_path || !out) {
@@ -220,15 +260,15 @@ int mi_tables_build(const char *json_path, int flags, const char *apo_text, doub
     Put(error, err, errcap);
     return MI_ERR_FILTER;
   }
-  std::vector<std::complex<double>> half;
+  miups::eq::EqFold fold;
   const bool withEq = apo_text && apo_text[0] != '\0';
   if (withEq) {
     miups::eq::EqProfile profile;
     miups::eq::parseEqString(apo_text, profile);
-    half = miups::eq::ComputeEqResponseHost(config.fftSize / 2 + 1, config.fftSize, fs_out, profile);
+    fold = miups::eq::FoldCascadeIntoTaps(taps, miups::eq::buildCascade(profile, fs_out));
   }
   auto *t = new mi_tables();
-  if (!miups::BuildTables(config, taps, withEq ? &half : nullptr, flags, &t->tables, &error)) {
+  if (!miups::BuildTables(config, taps, withEq ? &fold.fir : nullptr, flags, &t->tables, &error)) {
     delete t;
     Put(error, err, errcap);
     return MI_ERR_FILTER;

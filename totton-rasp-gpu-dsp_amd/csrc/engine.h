@@ -44,15 +44,31 @@ struct TableSet {
 };
 struct TablePool;  // retired sets of one filter, free for reuse
 
+// What folding an EQ into the FIR dropped (host/eq.h EqFold; include/mi_upsampler.h mi_eq_residual). active = false: no EQ.
+struct EqReport {
+  bool active = false;
+  double tailL1 = 0.0, tailL2 = 0.0, responseDev = 0.0;
+  bool tailComplete = true;
+  std::size_t taper = 0, firTaps = 0;
+  double limit = 0.0;
+  bool overLimit = false;
+};
+std::string EqReportWarning(const EqReport &r);  // "" unless r.overLimit
+
 // Device-resident filter state shared by engines.
 class DeviceFilter {
  public:
   ~DeviceFilter();
   static std::shared_ptr<DeviceFilter> Create(int device, const FilterConfig &config, std::vector<float> taps,
                                               int flags, std::string *error, const std::string &apoText = std::string(),
-                                              double fsOut = 0.0);
+                                              double fsOut = 0.0, double eqLimit = -1.0, bool eqStrict = false);
   // Swap in tables with (or without, when text is empty) the EQ folded in. On failure the current tables stay.
+  // The EQ becomes part of the FIR (cascade recursion over the taps, cut back to `taps` samples: host/eq.h). When the cut
+  // drops more than the limit (SetEqLimit, default -60 dB of the ideal response in the 1-norm) the change still goes
+  // through and EqReportWarning(eqReport()) says by how much -- unless the filter is strict: then it fails and nothing changes.
   bool SetEq(const std::string &apoText, double fsOut, std::string *error);
+  void SetEqLimit(double maxTailL1, bool strict);
+  EqReport eqReport() const;  // of the published tables
   // The same in two steps, for callers that change several filters together (MultiEngine: all slots or none): Stage
   // builds and uploads the new table set without touching the live one; Publish swaps it in (cannot fail). A staged
   // set that is dropped is freed.
@@ -60,6 +76,7 @@ class DeviceFilter {
     std::unique_ptr<TableSet> set;
     Geometry geo{};
     bool hasFused = false, fusedSplit = false, fusedNarrow = false, fusedR32 = false;
+    EqReport report;
   };
   bool Stage(const std::string &apoText, double fsOut, Staged *out, std::string *error);
   void Publish(Staged *staged);
@@ -81,7 +98,7 @@ class DeviceFilter {
 
  private:
   DeviceFilter() = default;
-  bool StageTables(const std::vector<std::complex<double>> *eqHalf, Staged *out, std::string *error);
+  bool StageTables(const std::vector<double> *totalFir, Staged *out, std::string *error);
 
   int device_ = 0;
   FilterConfig config_{};
@@ -95,6 +112,9 @@ class DeviceFilter {
   unsigned long long generation_ = 0;
   void *uploadStream_ = nullptr;  // hipStream_t, non-blocking: uploads never order against the audio streams
   bool failNextUpload_ = false;
+  double eqLimit_ = 1.0e-3;  // eq::kFoldDefaultLimit
+  bool eqStrict_ = false;
+  EqReport report_;
 };
 
 // Evaluate an APO profile's cascade on the device: bins 0..numBins-1 (fp64).

@@ -412,7 +412,7 @@ DeviceFilter::~DeviceFilter() {
 
 std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfig &config, std::vector<float> taps,
                                                    int flags, std::string *error, const std::string &apoText,
-                                                   double fsOut) {
+                                                   double fsOut, double eqLimit, bool eqStrict) {
   if (!UseDevice(device, error)) {
     return nullptr;
   }
@@ -428,6 +428,7 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
     f->flags_ |= kLoadInternalR32;
   }
   f->pool_ = std::make_shared<TablePool>();
+  f->SetEqLimit(eqLimit, eqStrict);
   if (!f->SetEq(apoText, fsOut, error)) {  // empty text: the plain filter
     return nullptr;
   }
@@ -435,7 +436,14 @@ std::shared_ptr<DeviceFilter> DeviceFilter::Create(int device, const FilterConfi
 }
 
 std::shared_ptr<DeviceFilter> DeviceFilter::Fork(const std::string &apoText, double fsOut, std::string *error) const {
-  return Create(device_, config_, taps_, flags_, error, apoText, fsOut);
+  double limit;
+  bool strict;
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    limit = eqLimit_;
+    strict = eqStrict_;
+  }
+  return Create(device_, config_, taps_, flags_, error, apoText, fsOut, limit, strict);
 }
 
 std::shared_ptr<const TableSet> DeviceFilter::tables() const {
@@ -450,9 +458,9 @@ unsigned long long DeviceFilter::generation() const {
 
 // Build the new tables on the host and upload them into a set that nothing reads. Whatever fails on the way, the
 // published set is untouched: engines keep running on the old spectrum and the error is returned.
-bool DeviceFilter::StageTables(const std::vector<std::complex<double>> *eqHalf, Staged *out, std::string *error) {
+bool DeviceFilter::StageTables(const std::vector<double> *totalFir, Staged *out, std::string *error) {
   FilterTables t;
-  if (!BuildTables(config_, taps_, eqHalf, flags_, &t, error)) {
+  if (!BuildTables(config_, taps_, totalFir, flags_, &t, error)) {
     return false;
   }
   if (!UseDevice(device_, error)) {
@@ -545,18 +553,60 @@ void DeviceFilter::Publish(Staged *staged) {
     fusedR32_ = staged->fusedR32;
   }
   staged->set->generation = ++generation_;
+  report_ = staged->report;
   cur_ = std::shared_ptr<const TableSet>(staged->set.release(), PoolReturn{pool_});
 }
 
 bool DeviceFilter::Stage(const std::string &apoText, double fsOut, Staged *out, std::string *error) {
+  out->report = EqReport{};
+  double limit;
+  bool strict;
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    limit = eqLimit_;
+    strict = eqStrict_;
+  }
+  out->report.limit = limit;
   if (apoText.empty()) {
     return StageTables(nullptr, out, error);
   }
+  if (!(fsOut > 0.0)) {
+    if (error) {
+      *error = "invalid EQ grid";
+    }
+    return false;
+  }
+  // The cascade becomes part of the FIR: recursion over the taps in fp64, cut back to `taps` samples (host/eq.h). The
+  // product stays a linear convolution -- nothing wraps inside a block -- and what the cut dropped is measured.
+  eq::EqProfile profile;
+  eq::parseEqString(apoText, profile);  // an empty profile evaluates to unity, as in the reference
+  eq::EqFold fold = eq::FoldCascadeIntoTaps(taps_, eq::buildCascade(profile, fsOut));
+  // ... and its response is held against the cascade's own, evaluated per bin on the device (computeEqResponseForFft)
   std::vector<std::complex<double>> half;
   if (!EqResponseDevice(device_, apoText, config_.fftSize / 2 + 1, config_.fftSize, fsOut, &half, error)) {
     return false;
   }
-  return StageTables(&half, out, error);
+  fold.responseDev = eq::ResponseDeviation(taps_, fold.fir, half, config_.fftSize);
+  EqReport &r = out->report;
+  r.active = true;
+  r.tailL1 = fold.tailL1;
+  r.tailL2 = fold.tailL2;
+  r.responseDev = fold.responseDev;
+  r.tailComplete = fold.tailComplete;
+  r.taper = fold.taper;
+  r.firTaps = fold.fir.size();
+  r.overLimit = fold.tailL1 > limit;
+  if (r.overLimit && strict) {
+    if (error) {
+      *error = EqReportWarning(r);
+    }
+    return false;
+  }
+  return StageTables(&fold.fir, out, error);
+}
+
+std::string EqReportWarning(const EqReport &r) {
+  return r.overLimit ? eq::FoldWarning(r.firTaps, r.tailL1, r.tailL2, r.tailComplete, r.limit) : std::string();
 }
 
 bool DeviceFilter::SetEq(const std::string &apoText, double fsOut, std::string *error) {
@@ -566,6 +616,17 @@ bool DeviceFilter::SetEq(const std::string &apoText, double fsOut, std::string *
   }
   Publish(&staged);
   return true;
+}
+
+void DeviceFilter::SetEqLimit(double maxTailL1, bool strict) {
+  std::lock_guard<std::mutex> lock(mu_);
+  eqLimit_ = maxTailL1 >= 0.0 ? maxTailL1 : eq::kFoldDefaultLimit;
+  eqStrict_ = strict;
+}
+
+EqReport DeviceFilter::eqReport() const {
+  std::lock_guard<std::mutex> lock(mu_);
+  return report_;
 }
 
 bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBins, std::size_t fullFft, double fsOut,

@@ -1,5 +1,7 @@
 #include "eq.h"
 
+#include "host_fft.h"
+
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -268,6 +270,128 @@ std::vector<double> ComputeEqMagnitudeHost(std::size_t numBins, std::size_t full
     }
   }
   return mag;
+}
+
+EqFold FoldCascadeIntoTaps(const std::vector<float> &taps, const Cascade &cascade) {
+  EqFold out;
+  const std::size_t n = taps.size();
+  out.fir.assign(n, 0.0);
+  std::vector<BiquadCoeffs> secs;  // bypass sections are the identity
+  for (const auto &s : cascade.sections) {
+    if (!(s.b0 == 1.0 && s.b1 == 0.0 && s.b2 == 0.0 && s.a1 == 0.0 && s.a2 == 0.0)) {
+      secs.push_back(s);
+    }
+  }
+  const std::size_t ns = secs.size();
+  // transposed direct form II per section: y = b0 x + s1; s1 = b1 x - a1 y + s2; s2 = b2 x - a2 y  (fp64: within 2e-11 of
+  // an 80-bit recursion at the worst corner the reference's validator accepts, Fc 10 Hz Q 100 at 768 kHz)
+  std::vector<double> s1(ns, 0.0), s2(ns, 0.0);
+  auto step = [&](double x) {
+    for (std::size_t i = 0; i < ns; ++i) {
+      const BiquadCoeffs &c = secs[i];
+      const double y = c.b0 * x + s1[i];
+      s1[i] = c.b1 * x - c.a1 * y + s2[i];
+      s2[i] = c.b2 * x - c.a2 * y;
+      x = y;
+    }
+    return x;
+  };
+  out.taper = n > 1 ? (n - 1) / 64 : 0;
+  double l1All = 0.0, l2All = 0.0, l1Cut = 0.0, l2Cut = 0.0;
+  for (std::size_t i = 0; i < n; ++i) {
+    const double v = step(static_cast<double>(taps[i]) * cascade.preampLinear);
+    double w = 1.0;
+    if (i + out.taper >= n) {
+      const double u = (static_cast<double>(i - (n - out.taper)) + 0.5) / static_cast<double>(out.taper);
+      w = 0.5 * (1.0 + std::cos(kPi * u));
+    }
+    out.fir[i] = v * w;
+    const double d = v - out.fir[i];
+    l1All += std::fabs(v);
+    l2All += v * v;
+    l1Cut += std::fabs(d);
+    l2Cut += d * d;
+  }
+  if (ns > 0 && l1All > 0.0) {
+    const std::size_t chunk = 4096;
+    const std::size_t maxChunks = static_cast<std::size_t>(kFoldTailWork / static_cast<double>(ns * chunk)) + 1;
+    double last = 0.0;
+    bool dead = false;
+    for (std::size_t c = 0; c < maxChunks && !dead; ++c) {
+      double a1 = 0.0, a2 = 0.0;
+      for (std::size_t i = 0; i < chunk; ++i) {
+        const double v = step(0.0);
+        a1 += std::fabs(v);
+        a2 += v * v;
+      }
+      l1All += a1;
+      l2All += a2;
+      l1Cut += a1;
+      l2Cut += a2;
+      last = a1;
+      dead = a1 <= 1e-17 * l1All;
+    }
+    if (!dead) {
+      out.tailComplete = false;
+      double rmax = 0.0;  // largest pole radius of the cascade
+      for (const auto &c : secs) {
+        const double disc = c.a1 * c.a1 - 4.0 * c.a2;
+        const double r = disc < 0.0 ? std::sqrt(std::max(c.a2, 0.0))
+                                    : std::max(std::fabs(-c.a1 + std::sqrt(disc)), std::fabs(-c.a1 - std::sqrt(disc))) / 2.0;
+        rmax = std::max(rmax, r);
+      }
+      const double rho = std::pow(std::min(rmax, 1.0), static_cast<double>(chunk));
+      const double rest = rho < 1.0 - 1e-12 ? last * rho / (1.0 - rho) : 1e300;
+      l1All += rest;
+      l1Cut += rest;
+      const double rest2 = rho < 1.0 - 1e-12 ? (last * last / static_cast<double>(chunk)) * rho * rho / (1.0 - rho * rho) : 1e300;
+      l2All += rest2;
+      l2Cut += rest2;
+    }
+  }
+  out.tailL1 = l1All > 0.0 ? l1Cut / l1All : 0.0;
+  out.tailL2 = l2All > 0.0 ? std::sqrt(l2Cut / l2All) : 0.0;
+  return out;
+}
+
+double ResponseDeviation(const std::vector<float> &taps, const std::vector<double> &fir,
+                         const std::vector<std::complex<double>> &eqHalf, std::size_t fftSize) {
+  const std::size_t N = fftSize;
+  if (N < 2 || eqHalf.size() != N / 2 + 1 || taps.size() > N || fir.size() > N) {
+    return 0.0;
+  }
+  std::vector<std::complex<double>> z(N, std::complex<double>(0.0, 0.0));
+  for (std::size_t i = 0; i < taps.size(); ++i) {
+    z[i] = std::complex<double>(static_cast<double>(taps[i]), 0.0);
+  }
+  for (std::size_t i = 0; i < fir.size(); ++i) {
+    z[i] += std::complex<double>(0.0, fir[i]);
+  }
+  miups::Fft64(z, false);
+  double worst = 0.0, peak = 0.0;
+  for (std::size_t k = 0; k <= N / 2; ++k) {
+    const std::complex<double> a = z[k], b = std::conj(z[(N - k) % N]);
+    const std::complex<double> hFir = 0.5 * (a + b);                                  // spectrum of the real part
+    const std::complex<double> hUsed = std::complex<double>(0.0, -0.5) * (a - b);     // ... of the imaginary part
+    const std::complex<double> ideal = hFir * eqHalf[k];
+    worst = std::max(worst, std::abs(hUsed - ideal));
+    peak = std::max(peak, std::abs(ideal));
+  }
+  return peak > 0.0 ? worst / peak : 0.0;
+}
+
+std::string FoldWarning(std::size_t firTaps, double tailL1, double tailL2, bool tailComplete, double limit) {
+  if (!(tailL1 > limit)) {
+    return std::string();
+  }
+  auto db = [](double v) { return v > 0.0 ? 20.0 * std::log10(v) : -400.0; };
+  std::ostringstream m;
+  m.setf(std::ios::fixed);
+  m.precision(1);
+  m << "EQ cut to " << firTaps << " taps drops " << db(tailL1) << " dB of the ideal cascade response (limit "
+    << db(limit) << " dB, 2-norm " << db(tailL2) << " dB" << (tailComplete ? "" : ", tail estimated")
+    << "): a band this low or this narrow rings longer than the filter is; use a longer filter or a wider band";
+  return m.str();
 }
 
 }  // namespace miups::eq

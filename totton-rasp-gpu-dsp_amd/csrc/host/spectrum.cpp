@@ -241,9 +241,8 @@ bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *error
   return true;
 }
 
-bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
-                 const std::vector<std::complex<double>> *eq_half, int flags, FilterTables *out,
-                 std::string *errorMessage) {
+bool BuildTables(const FilterConfig &config, const std::vector<float> &taps, const std::vector<double> *totalFir,
+                 int flags, FilterTables *out, std::string *errorMessage) {
   if (!BuildGeometry(config, &out->geo, errorMessage)) {
     return false;
   }
@@ -256,50 +255,31 @@ bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
     }
     return false;
   }
-  if (eq_half && eq_half->size() != N / 2 + 1) {
+  if (totalFir && totalFir->size() != taps.size()) {
     if (errorMessage) {
-      *errorMessage = "EQ response must cover bins 0..fft_size/2";
+      *errorMessage = "the EQ-folded filter must keep the tap count (fft_size - block_size == taps - 1)";
     }
     return false;
   }
 
   // ---- total impulse response on the N-point circle -----------------------
+  // Without the compat flag it is the FIR itself: `taps` samples, zero beyond -- a linear convolution, EQ included.
   std::vector<double> h(N, 0.0);
   const bool compat = (flags & kLoadRefCompatSpectrum) != 0;
-  if (!eq_half && !compat) {
+  if (!compat) {
     for (std::size_t i = 0; i < taps.size(); ++i) {
-      h[i] = static_cast<double>(taps[i]);
+      h[i] = totalFir ? (*totalFir)[i] : static_cast<double>(taps[i]);
     }
   } else {
-    std::vector<std::complex<double>> H(N);
-    if (compat) {
-      std::vector<std::complex<float>> H32(N, std::complex<float>(0.0f, 0.0f));
-      for (std::size_t i = 0; i < taps.size(); ++i) {
-        H32[i] = std::complex<float>(taps[i], 0.0f);
-      }
-      FftRefCompat32(H32, false);
-      for (std::size_t i = 0; i < N; ++i) {
-        H[i] = std::complex<double>(H32[i].real(), H32[i].imag());
-      }
-    } else {
-      for (std::size_t i = 0; i < N; ++i) {
-        H[i] = i < taps.size() ? std::complex<double>(taps[i], 0.0) : std::complex<double>(0.0, 0.0);
-      }
-      Fft64(H, false);
+    // what the reference would multiply by if it were handed these coefficients: its fp32 recurrence FFT of them
+    std::vector<std::complex<float>> H32(N, std::complex<float>(0.0f, 0.0f));
+    for (std::size_t i = 0; i < taps.size(); ++i) {
+      H32[i] = std::complex<float>(totalFir ? static_cast<float>((*totalFir)[i]) : taps[i], 0.0f);
     }
-    if (eq_half) {
-      const auto &e = *eq_half;
-      for (std::size_t k = 0; k < N; ++k) {
-        std::complex<double> r;
-        if (k == 0 || k == N / 2) {
-          r = std::complex<double>(e[k].real(), 0.0);
-        } else if (k < N / 2) {
-          r = e[k];
-        } else {
-          r = std::conj(e[N - k]);
-        }
-        H[k] *= r;
-      }
+    FftRefCompat32(H32, false);
+    std::vector<std::complex<double>> H(N);
+    for (std::size_t i = 0; i < N; ++i) {
+      H[i] = std::complex<double>(H32[i].real(), H32[i].imag());
     }
     // The reference keeps Re(IFFT(X*H)); for real x that equals filtering with
     // the real part of IFFT(H), whatever asymmetry rounding left in H.

@@ -69,10 +69,9 @@ int FusedBlockA(int tau, int log2k, bool r32);  // first block of thread tau in 
 
 bool BuildGeometry(const FilterConfig &config, Geometry *geo, std::string *errorMessage);
 
-// eq_half: optional response on bins 0..N/2 of the N-point grid (fp64); the
-// total spectrum is H_fir[k] * EQ[k] on all N bins (Hermitian extension).
-bool BuildTables(const FilterConfig &config, const std::vector<float> &taps,
-                 const std::vector<std::complex<double>> *eq_half, int flags, FilterTables *out,
-                 std::string *errorMessage);
+// totalFir: optional replacement of the taps by the EQ-folded FIR (fp64, SAME length: eq::FoldCascadeIntoTaps), so the
+// product stays a linear convolution with at most `taps` samples and fft_size - block_size == taps - 1 keeps holding.
+bool BuildTables(const FilterConfig &config, const std::vector<float> &taps, const std::vector<double> *totalFir,
+                 int flags, FilterTables *out, std::string *errorMessage);
 
 }  // namespace miups

@@ -56,6 +56,13 @@ class MultiEngine {
   // every slot's filter, all or nothing: the new tables of ALL slots are built first, then published together; if one
   // build fails no slot changes (streams of one run never play with different EQs)
   bool SetEq(const std::string &apoText, double fsOut, std::string *error);
+  // what the EQ fold dropped (every slot folds the same taps: slot 0's report) and the limit / strictness of all slots
+  EqReport eqReport() const { return slots_[0]->filter->eqReport(); }
+  void SetEqLimit(double maxTailL1, bool strict) {
+    for (auto &s : slots_) {
+      s->filter->SetEqLimit(maxTailL1, strict);
+    }
+  }
   bool Reset(std::string *error);
   int slots() const { return static_cast<int>(slots_.size()); }
   int streams() const { return streams_; }

@@ -223,8 +223,17 @@ struct Pipeline {
     if (engine) mi_engine_destroy(engine);
     if (filter) mi_filter_release(filter);
   }
+  // An EQ whose ringing does not fit the filter still goes through (the cascade is cut to the filter's tap count); the
+  // library says how much of the ideal response the cut dropped, and that goes to stderr (include/mi_upsampler.h).
   bool SetEq(const std::string &text) {
-    return (multi ? mi_multi_set_eq(multi, text.c_str(), eqRate) : mi_filter_set_eq(filter, text.c_str(), eqRate)) == MI_OK;
+    if ((multi ? mi_multi_set_eq(multi, text.c_str(), eqRate) : mi_filter_set_eq(filter, text.c_str(), eqRate)) != MI_OK) {
+      return false;
+    }
+    const char *warning = mi_ups_last_error();
+    if (warning && warning[0]) {
+      std::cerr << "EQ warning: " << warning << "\n";
+    }
+    return true;
   }
   // `blocks` blocks of every stream; streams are `inStride` / `outStride` bytes apart in the host buffers
   bool Process(const void *in, size_t inStride, void *out, size_t outStride, size_t blocks) {
