@@ -206,6 +206,14 @@ unsigned long long mi_engine_last_generation(const mi_engine *e);
 /* test hook: the next table upload of this filter fails after the host-side build (tests that a failed EQ change
  * leaves the filter usable) */
 void mi_debug_fail_next_table_upload(mi_filter *f);
+/* The rule the host-buffer paths rest on: never two asynchronous copies in flight on host ranges that are
+ * not page-locked and may share a page. Every copy mi_engine_process_host / mi_multi_process_host / mi_ups_process_block
+ * issues is audited against it; this returns how many broke it since the process started. Tests require 0. */
+unsigned long long mi_debug_unsafe_host_copies(void);
+/* test hooks: the next mi_engine_process_host (of slot `slot`'s engine for the multi form) fails right after issuing the
+ * host-to-device copies of its sub-batch `sub_batch` (0-based), as if the runtime had refused a call there. The call must
+ * return an error only after every copy in flight has completed, and the engine stays usable (reset it). */
+void mi_debug_fail_host_call_at(mi_engine *e, int sub_batch);
 /* diagnostic: on SIGABRT print the native stack of the aborting thread to stderr, then continue to the previous handler
  * (the HIP runtime aborts without a message on some internal failures) */
 void mi_debug_install_abort_backtrace(void);
@@ -275,6 +283,8 @@ int mi_multi_partition_channels(int channels, int slots, int *first_channel_of_s
 int mi_multi_worker_cpus(const mi_multi *m, int slot, char *out, size_t cap);
 /* test hook: the next mi_multi_set_eq fails while building slot `slot`'s tables */
 void mi_debug_multi_fail_next_eq_on_slot(mi_multi *m, int slot);
+/* test hook: mi_debug_fail_host_call_at for the engine of slot `slot` */
+void mi_debug_multi_fail_host_call_at(mi_multi *m, int slot, int sub_batch);
 /* the partition itself (pure): slot_of_stream[s] = s mod slots */
 int mi_multi_partition(int streams, int slots, int *slot_of_stream);
 

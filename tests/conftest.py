@@ -38,6 +38,17 @@ def ups():
     return m
 
 
+@pytest.fixture(scope="session", autouse=True)
+def host_copy_rule_held(request):
+    """At the end of a session on a GPU box: no asynchronous host copy of the library broke the rule of DESIGN 4 (never two
+    in flight on unpinned host ranges that may share a page). Counted by the library itself, process-wide."""
+    yield
+    if "totton_rasp_gpu_dsp_amd" in sys.modules:
+        m = sys.modules["totton_rasp_gpu_dsp_amd"]
+        if m.device_count() > 0:
+            assert m.unsafe_host_copies() == 0, "a host copy broke the one-in-flight-per-unpinned-page rule"
+
+
 @pytest.fixture(scope="session")
 def O():
     import oracle

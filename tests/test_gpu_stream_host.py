@@ -23,6 +23,16 @@ PROFILES = json.loads((GOLDEN / "g4_eq_profiles.json").read_text())
 F4X = ROOT / "data" / "coefficients" / "filter_44k_4x_80000_min_phase.json"
 
 
+@pytest.fixture(autouse=True)
+def no_unsafe_host_copy(ups):
+    """The rule the host paths rest on (profiles/r03_r_multi_fault.txt): never two asynchronous copies in flight
+    on host ranges that are not page-locked and may share a page. The library audits every copy it issues against it
+    (engine.hip HostCopyAudit); no test of this module may raise the count."""
+    before = ups.unsafe_host_copies()
+    yield
+    assert ups.unsafe_host_copies() == before, "a host copy broke the one-in-flight-per-unpinned-page rule"
+
+
 def synth(streams, frames, channels, seed=0):
     x = np.clip(np.random.default_rng(seed).standard_normal((streams, frames, channels)) * 0.1, -1, 1)
     return np.round(x * 2**31).clip(-2**31, 2**31 - 1).astype("<i4")
@@ -189,11 +199,13 @@ def test_failed_eq_rebuild_keeps_the_old_tables(ups, gpu):
 
 
 def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
-    """A thread streams 64-block calls back to back on its own HIP stream while the main thread swaps the EQ four
+    """A thread streams 64-block calls back to back on its own HIP stream while the main thread swaps the EQ sixteen
     times. A swap must not hold the stream up: it uploads beside the live tables on a private stream and never
-    synchronises the device. Judged on the calls that OVERLAP a swap: a swap that stalls the stream shows at every swap,
-    so at most one of the four may coincide with a slow call (the box has hiccups of 3-10 ms about once in 10 000 calls
-    whether or not a swap is running: scripts/eq_swap_stall.py)."""
+    synchronises the device. Judged on the calls that OVERLAP a swap, with zero tolerance for a pattern: a swap that
+    stalls the stream shows at every swap, the box's own hiccups (3-10 ms about once in 10 000 calls whether or not a swap
+    is running: scripts/eq_swap_stall.py) would almost never meet one. So at most ONE of sixteen swaps may coincide with a
+    slow call (a real stall rate of 25 % fails with probability 0.94) and that one stays within 50 ms; the bound on every
+    other overlapped call stays 10 x the median + 5 ms."""
     from bench import Hip
 
     hip = Hip()
@@ -221,11 +233,11 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     time.sleep(0.3)
     n_before = len(times)
     swaps = []
-    for k in range(4):
+    for k in range(16):
         t0 = time.perf_counter()
         filt.set_eq(PROFILES["opra10"] if k % 2 == 0 else "", 705600.0)
         swaps.append((t0, time.perf_counter()))
-        time.sleep(0.05)
+        time.sleep(0.03)
     time.sleep(0.2)
     stop.set()
     t.join()
@@ -234,9 +246,10 @@ def test_eq_swap_does_not_stall_a_running_stream(ups, gpu):
     assert n_before > 20 and len(times) > n_before + 20
     typical = float(np.median(times))
     limit = 10 * typical + 5e-3
-    stalled = [k for k, (a, b) in enumerate(swaps)
-               if any(t1 - t0 > limit for t0, t1 in spans[5:] if t1 >= a and t0 <= b)]
+    over = [[t1 - t0 for t0, t1 in spans[5:] if t1 >= a and t0 <= b] for a, b in swaps]
+    stalled = [k for k, v in enumerate(over) if v and max(v) > limit]
     assert len(stalled) <= 1, (stalled, typical, [round(b - a, 4) for a, b in swaps])
+    assert all(max(v) < 0.05 for v in over if v), [round(max(v), 4) for v in over if v]  # the tolerated one: a hiccup, not a stall
     assert max(times[5:]) < 0.25, max(times[5:])  # and nothing ever hangs
 
 
@@ -475,3 +488,92 @@ def test_cli_null_endpoints_run_the_filter_in_real_time(ups):
     blocks = int(tail.split(" periods, ")[1].split(" blocks")[0])
     assert blocks >= 2, out
     assert "overflows 0/0" in tail
+
+
+# ---- the rule behind the pageable-copy fix, tested as a rule -----------------------------------------------------------
+def test_host_path_error_exit_drains_before_the_pins_go(ups, gpu):
+    """A failure in sub-batch 2 of 4 of a call on PAGEABLE buffers (mi_debug_fail_host_call_at): sub-batches 0 and 1 have
+    copies in flight on the h2d / d2h streams when the call gives up. It must return an error only after they have
+    completed (the per-call page-lock is released on the way out; DMA on an unpinned range is the GPU memory fault of
+    profiles/r03_r_multi_fault.txt), leave the audit count at 0, and leave the engine usable: after a reset the same
+    input gives the bytes of an undisturbed engine."""
+    path = ROOT / "data" / "coefficients" / "filter_48k_16x_80000_min_phase.json"
+    streams, channels, blocks = 4, 64, 4     # 256 channel-blocks per block: sub-batches of ONE block, four of them
+    filt = ups.Filter(path, device=gpu)
+    eng = ups.Engine(filt, streams, channels, ups.PCM_S16, ups.PCM_S16)
+    ref = ups.Engine(filt, streams, channels, ups.PCM_S16, ups.PCM_S16)
+    x = (np.random.default_rng(3).standard_normal((streams, blocks * eng.in_frames, channels)) * 2000).astype("<i2")
+    want = ref.process_host(x, blocks).copy()
+    before = ups.unsafe_host_copies()
+    ups.lib.mi_debug_fail_host_call_at(eng._h, 2)
+    out = np.zeros(eng.out_bytes(blocks) * streams, dtype=np.uint8)   # pageable, as x is
+    with pytest.raises(ups.UpsamplerError, match="injected by test hook"):
+        eng.process_host(x, blocks, out=out)
+    # sub-batches 0 and 1 were copied out before the call returned: their bytes are there, in every stream
+    ob = eng.out_bytes(1)
+    for s_ in range(streams):
+        row = slice(s_ * eng.out_bytes(blocks), s_ * eng.out_bytes(blocks) + 2 * ob)
+        np.testing.assert_array_equal(out[row], want[row])
+    assert ups.unsafe_host_copies() == before
+    del out                                    # the caller may free its buffer at once: nothing is in flight on it
+    eng.reset()
+    np.testing.assert_array_equal(eng.process_host(x, blocks), want)
+
+
+def test_multi_engine_worker_failure_leaves_no_copy_in_flight(ups, gpu):
+    """The same injected failure inside ONE worker of a time-split MultiEngine on pageable buffers: mi_multi_process_host
+    returns the slot's error after every worker has returned (pending_ == 0) and only then releases the call's page-lock;
+    the siblings' ranges are complete, the audit stays at 0, and after a reset the object works again."""
+    path = ROOT / "data" / "coefficients" / "filter_48k_16x_80000_min_phase.json"
+    streams, channels, blocks = 2, 128, 8     # per slot: 4 blocks in 4 sub-batches
+    multi = ups.MultiEngine(path, [0, 0], streams, channels, ups.PCM_S16, ups.PCM_S16, split_time=True)
+    filt = ups.Filter(path, device=gpu)
+    one = ups.Engine(filt, streams, channels, ups.PCM_S16, ups.PCM_S16)
+    x = (np.random.default_rng(4).standard_normal((streams, blocks * one.in_frames, channels)) * 2000).astype("<i2")
+    want = one.process_host(x, blocks).copy()
+    before = ups.unsafe_host_copies()
+    ups.lib.mi_debug_multi_fail_host_call_at(multi._h, 1, 1)
+    with pytest.raises(ups.UpsamplerError, match="injected by test hook"):
+        multi.process_host(x, blocks)
+    assert ups.unsafe_host_copies() == before
+    multi.reset()
+    np.testing.assert_array_equal(multi.process_host(x, blocks), want)
+
+
+def test_single_block_call_on_buffers_that_share_a_page(ups, O, gpu):
+    """mi_ups_process_block with input and output carved out of ONE allocation so that they share a page (heap
+    neighbours do): the pair is two copies on pageable memory; the copy in is waited for before the copy out is issued
+    (advisor finding of round 3). Audit 0, result = the result on separate buffers."""
+    u = ups.StreamingUpsampler(gpu)
+    assert u.load_filter(F4X)[0]
+    cfg = u.config
+    nin, B = cfg["block_size"] // cfg["upsample_factor"], cfg["block_size"]
+    x = real_input(8, nin)
+    want = u.process_block(x)
+    u.reset()
+    both = np.zeros(nin + B, dtype=np.float32)      # input then output, back to back: the boundary page is shared
+    both[:nin] = x
+    before = ups.unsafe_host_copies()
+    n = ups.lib.mi_ups_process_block(u._h, both[:nin].ctypes.data_as(C.POINTER(C.c_float)), nin,
+                                     both[nin:].ctypes.data_as(C.POINTER(C.c_float)), B)
+    assert n == B and ups.unsafe_host_copies() == before
+    np.testing.assert_array_equal(both[nin:], want)
+
+
+def test_page_lock_check_covers_the_extent(ups, gpu):
+    """A buffer whose HEAD is registered but whose tail is not (the caller registered a shorter length) must not be taken
+    as page-locked: the call registers... cannot (partly registered) and falls back to one copy at a time. Bytes equal to
+    the plain call, audit 0."""
+    filt = ups.Filter(F4X, device=gpu)
+    streams, channels, blocks = 2, 2, 3
+    eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
+    ref = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
+    x = synth(streams, blocks * eng.in_frames, channels, seed=5)
+    want = ref.process_host(x, blocks).copy()
+    raw = x.view(np.uint8).reshape(-1)
+    head = ups.RegisteredBuffer(raw[: 1 << 16])          # first 64 KiB only
+    before = ups.unsafe_host_copies()
+    got = eng.process_host(raw, blocks)
+    head.close()
+    assert ups.unsafe_host_copies() == before
+    np.testing.assert_array_equal(got, want)

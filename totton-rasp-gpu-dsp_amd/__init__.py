@@ -105,6 +105,9 @@ def _load():
         "mi_ups_process_block": (C.c_long, [vp, f32p, sz, f32p, sz]),
         "mi_ups_reset": (i32, [vp]),
         "mi_ups_set_eq": (i32, [vp, cp, dbl]),
+        "mi_debug_unsafe_host_copies": (C.c_ulonglong, []),
+        "mi_debug_fail_host_call_at": (None, [vp, i32]),
+        "mi_debug_multi_fail_host_call_at": (None, [vp, i32, i32]),
         "mi_ups_eq_residual": (i32, [vp, C.POINTER(_EqResidual)]),
         "mi_ups_set_eq_limit": (i32, [vp, dbl, i32]),
         "mi_filter_eq_residual": (i32, [vp, C.POINTER(_EqResidual)]),
@@ -232,7 +235,13 @@ EXPORTED_SYMBOLS = [
     "mi_tables_free", "mi_tables_block_b", "mi_lds_swizzle", "mi_fused_set_of_block", "mi_fused_block_a",
     "mi_fused_plan_radices", "mi_ups_eq_residual", "mi_ups_set_eq_limit", "mi_filter_eq_residual",
     "mi_filter_set_eq_limit", "mi_multi_eq_residual", "mi_multi_set_eq_limit", "mi_eq_fold_host",
+    "mi_debug_unsafe_host_copies", "mi_debug_fail_host_call_at", "mi_debug_multi_fail_host_call_at",
 ]
+
+
+def unsafe_host_copies() -> int:
+    """Asynchronous host copies that broke the one-in-flight-per-unpinned-page rule since the process started (must be 0)."""
+    return int(lib.mi_debug_unsafe_host_copies())
 
 
 def last_error() -> str:

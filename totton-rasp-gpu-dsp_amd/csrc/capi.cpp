@@ -558,6 +558,20 @@ void AbortBacktrace(int sig) {
   raise(sig);
 }
 }  // namespace
+unsigned long long mi_debug_unsafe_host_copies(void) { return miups::UnsafeHostCopies(); }
+
+void mi_debug_fail_host_call_at(mi_engine *e, int sub_batch) {
+  if (e && e->engine) {
+    e->engine->FailHostCallAtForTest(sub_batch);
+  }
+}
+
+void mi_debug_multi_fail_host_call_at(mi_multi *m, int slot, int sub_batch) {
+  if (m && m->multi) {
+    m->multi->FailHostCallAtForTest(slot, sub_batch);
+  }
+}
+
 void mi_debug_install_abort_backtrace(void) {
   // MIUPS_ABORT_BACKTRACE=<path>: where to write (a test runner may have redirected descriptor 2); anything else: stderr
   if (const char *path = std::getenv("MIUPS_ABORT_BACKTRACE")) {

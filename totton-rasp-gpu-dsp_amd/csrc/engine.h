@@ -121,6 +121,17 @@ class DeviceFilter {
 bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBins, std::size_t fullFft, double fsOut,
                       std::vector<std::complex<double>> *out, std::string *error);
 
+// Experiment switches of profiles/ (MIUPS_EXP_*): read from the environment ONCE, when an engine is created -- never on
+// the per-call path. Defaults are the measured best; none changes results.
+struct ExpSwitches {
+  bool stereoExt = false, park = false, noPhaseParts = false, noTiledInterleave = false, noRowsInterleave = false,
+       noSplitPlanar = false, noTwoLevel = false, twoLevelNoPlanar = false, twoLevelStoreForward = false,
+       hostThreeStreams = false;
+  int tileTi = 0, chunkMb = 0, chunkRounds = 0, twoLevelBudgetMb = 0, hostSubBatches = 0;
+  int pipeline = -1;  // 0 = never, 1 = always, -1 = by shape
+  static ExpSwitches FromEnvironment();
+};
+
 class Engine {
  public:
   ~Engine();
@@ -166,6 +177,9 @@ class Engine {
   // ProcessHost of a single sub-batch on the engine's own stream (default) or through the three-stream pipeline; the
   // phase-split kernels for small calls (PickChannelGroup) on or off. Test / experiment hooks: both default to on.
   void SetHostOneStream(bool on) { hostOneStream_ = on; }
+  // test hook: the next ProcessHost fails after issuing the host-to-device copies of sub-batch `j` (0-based), as if the
+  // runtime had refused a call there -- the error path must drain its streams before the caller's buffers are unpinned
+  void FailHostCallAtForTest(int j) { failAtSubBatch_ = j; }
   void SetSmallCallSplit(bool on) { smallCallSplit_ = on; }
   // workgroups per (block, stream, channel) of the latest fused call: 0 = the plain form, >= 2 = phase-split (small calls)
   int lastPhaseParts() const { return parts_; }
@@ -200,11 +214,13 @@ class Engine {
   bool MarkDone(void *stream, std::shared_ptr<const TableSet> tabs, std::string *error);
 
   std::shared_ptr<DeviceFilter> filter_;
+  ExpSwitches exp_;
   int streams_ = 1, channels_ = 1, inFmt_ = kF32, outFmt_ = kF32;
   bool fused_ = false;
   int cuCount_ = 256;
   int cg_ = 1, groups_ = 1;        // fused path: channels per workgroup, groups per stream
   bool hostOneStream_ = true;
+  int failAtSubBatch_ = -1;
   bool smallCallSplit_ = true;
   bool lastTwoLevel_ = false;
   int parts_ = 0;                  // fused path, small calls: workgroups per (block, stream, channel) (phase-split), else 0
@@ -250,6 +266,12 @@ class Engine {
   long long timingCalls_ = 0;
   int timingEvery_ = 1;
 };
+
+// Both ends of [p, p + bytes) are page-locked host memory (the first byte alone proves nothing about the extent).
+bool HostRangePageLocked(const void *p, std::size_t bytes);
+// How many asynchronous host copies ProcessHost has issued, process-wide, on a range that was not page-locked while
+// another such copy that may share a page with it was still in flight. The rule of DESIGN 4 says: never. Tests assert 0.
+unsigned long long UnsafeHostCopies();
 
 // Pinned host memory for ProcessHost callers (hipHostMalloc / hipHostFree).
 void *HostAlloc(std::size_t bytes, std::string *error);

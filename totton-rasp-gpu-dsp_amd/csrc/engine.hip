@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -133,7 +134,7 @@ cf *StagedFft(cf *a, cf *b, const cf *tw, int log2k, long long rows, hipStream_t
 // The two-level path (device/kernels_tiled.h) for `n` work items starting at item0 (pair-major: whole pairs):
 // PCM -> A (work0) -> X (work1) -> per phase B (work2) -> staging planes.
 template <int LOG2M, int K1>
-bool LaunchTiledSized(const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes,
+bool LaunchTiledSized(int newestFirst, const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes,
                       int item0, int n, hipStream_t st, std::string *error) {
   using Cfg = TiledRowCfg<LOG2M>;
   static_assert(Cfg::M * K1 <= (1 << 18), "two-level sizes");
@@ -158,19 +159,18 @@ bool LaunchTiledSized(const Geometry &g, const IoDesc &io, const TableSet &tabs,
   hipLaunchKernelGGL((tiled_row_inverse_kernel<LOG2M, K1>), dim3(static_cast<unsigned>(n) * g.P * K1), dim3(Cfg::T),
                      Cfg::LDS_BYTES, st, g, spectral, tabs.tw, B);
   const long long rows = static_cast<long long>(n) * g.P;
-  const int newestFirst = std::getenv("MIUPS_EXP_TWO_LEVEL_STORE_FORWARD") == nullptr ? 1 : 0;  // experiment switch (profiles/)
   hipLaunchKernelGGL((tiled_store_kernel<K1>), dim3(Blocks(rows * M2, threads)), dim3(threads), 0, st, g, tabs.tw, B, planes, rows,
                      newestFirst);
   return HipOk(hipGetLastError(), "two-level transform kernels", error);
 }
 
-bool LaunchTiled(const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes, int item0,
-                 int n, hipStream_t st, std::string *error) {
+bool LaunchTiled(int newestFirst, const Geometry &g, const IoDesc &io, const TableSet &tabs, cf *A, cf *X, cf *B, float *planes,
+                 int item0, int n, hipStream_t st, std::string *error) {
   switch (g.log2k) {
-    case 15: return LaunchTiledSized<11, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
-    case 16: return LaunchTiledSized<12, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
-    case 17: return LaunchTiledSized<13, 16>(g, io, tabs, A, X, B, planes, item0, n, st, error);
-    case 18: return LaunchTiledSized<13, 32>(g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 15: return LaunchTiledSized<11, 16>(newestFirst, g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 16: return LaunchTiledSized<12, 16>(newestFirst, g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 17: return LaunchTiledSized<13, 16>(newestFirst, g, io, tabs, A, X, B, planes, item0, n, st, error);
+    case 18: return LaunchTiledSized<13, 32>(newestFirst, g, io, tabs, A, X, B, planes, item0, n, st, error);
     default: break;
   }
   if (error) {
@@ -667,8 +667,11 @@ bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBin
          HipOk(hipMalloc(reinterpret_cast<void **>(&dOut), numBins * sizeof(double2)), "hipMalloc", error);
   }
   if (ok && nsec) {
+    // pageable source, and a pageable destination follows on the same stream (out->data() below): one such copy in flight
+    // at a time (see FillArray) -- the upload is waited for before anything else is enqueued
     ok = HipOk(hipMemcpyAsync(dSec, cascade.sections.data(), nsec * sizeof(eq::BiquadCoeffs), hipMemcpyHostToDevice, st),
-               "hipMemcpyAsync", error);
+               "hipMemcpyAsync", error) &&
+         HipOk(hipStreamSynchronize(st), "hipStreamSynchronize(eq sections)", error);
   }
   if (ok) {
     const double df = fsOut / static_cast<double>(fullFft);
@@ -745,6 +748,34 @@ Engine::~Engine() {
   }
 }
 
+ExpSwitches ExpSwitches::FromEnvironment() {
+  ExpSwitches x;
+  auto on = [](const char *name) { return std::getenv(name) != nullptr; };
+  auto num = [](const char *name) {
+    const char *v = std::getenv(name);
+    return v ? std::max(1, std::atoi(v)) : 0;
+  };
+  x.stereoExt = on("MIUPS_EXP_STEREO_EXT");
+  x.park = on("MIUPS_EXP_PARK");
+  x.noPhaseParts = on("MIUPS_EXP_NO_PHASE_PARTS");
+  x.noTiledInterleave = on("MIUPS_EXP_NO_TILED_INTERLEAVE");
+  x.noRowsInterleave = on("MIUPS_EXP_NO_ROWS_INTERLEAVE");
+  x.noSplitPlanar = on("MIUPS_EXP_NO_SPLIT_PLANAR");
+  x.noTwoLevel = on("MIUPS_EXP_NO_TWO_LEVEL");
+  x.twoLevelNoPlanar = on("MIUPS_EXP_TWO_LEVEL_NO_PLANAR");
+  x.twoLevelStoreForward = on("MIUPS_EXP_TWO_LEVEL_STORE_FORWARD");
+  x.hostThreeStreams = on("MIUPS_EXP_HOST_THREE_STREAMS");
+  x.tileTi = num("MIUPS_EXP_TILE_TI");
+  x.chunkMb = num("MIUPS_EXP_CHUNK_MB");
+  x.chunkRounds = num("MIUPS_EXP_CHUNK_ROUNDS");
+  x.twoLevelBudgetMb = num("MIUPS_EXP_TWO_LEVEL_BUDGET_MB");
+  x.hostSubBatches = num("MIUPS_EXP_HOST_SUBBATCHES");
+  if (const char *v = std::getenv("MIUPS_EXP_PIPELINE")) {
+    x.pipeline = v[0] == '1' ? 1 : 0;
+  }
+  return x;
+}
+
 std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int streams, int channels, int inFmt,
                                        int outFmt, std::string *error) {
   auto bad = [&](const char *m) -> std::unique_ptr<Engine> {
@@ -767,6 +798,7 @@ std::unique_ptr<Engine> Engine::Create(std::shared_ptr<DeviceFilter> filter, int
   }
   std::unique_ptr<Engine> e(new Engine());
   e->filter_ = std::move(filter);
+  e->exp_ = ExpSwitches::FromEnvironment();
   e->streams_ = streams;
   e->channels_ = channels;
   e->inFmt_ = inFmt;
@@ -924,15 +956,17 @@ bool Engine::LoadHistoryHost(const void *h, std::size_t streamStride, std::strin
   if (!OrderAfterLast(own_, error)) {
     return false;
   }
-  for (int s = 0; s < streams_ && histStride_ > 0; ++s) {
-    MI_HIP(hipMemcpyAsync(static_cast<char *>(hist_[cur_]) + static_cast<std::size_t>(s) * histStride_,
-                          static_cast<const char *>(h) + static_cast<std::size_t>(s) * streamStride, histStride_,
-                          hipMemcpyHostToDevice, own));
-    if (streams_ > 1) {
-      MI_HIP(hipStreamSynchronize(own));  // neighbouring rows of a pageable buffer: one copy in flight (see FillArray)
-    }
+  bool ok = true;
+  for (int s = 0; ok && s < streams_ && histStride_ > 0; ++s) {
+    ok = HipOk(hipMemcpyAsync(static_cast<char *>(hist_[cur_]) + static_cast<std::size_t>(s) * histStride_,
+                              static_cast<const char *>(h) + static_cast<std::size_t>(s) * streamStride, histStride_,
+                              hipMemcpyHostToDevice, own),
+               "hipMemcpyAsync(history)", error) &&
+         // neighbouring rows of a pageable buffer: one copy in flight (see FillArray)
+         (streams_ <= 1 || HipOk(hipStreamSynchronize(own), "hipStreamSynchronize(history)", error));
   }
-  if (!MarkDone(own_, nullptr, error)) {
+  if (!ok || !MarkDone(own_, nullptr, error)) {
+    (void)hipStreamSynchronize(own);  // no copy from the caller's buffer is left in flight behind a failure
     return false;
   }
   // the caller may reuse (or change) its buffer when this returns
@@ -1030,7 +1064,7 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   const std::size_t capacity = static_cast<std::size_t>(cuCount_) * std::min(byLds, byWaves);
   wgCapacity_ = std::max<std::size_t>(capacity, 1);
   bool whole = channels_ == 1 || (channels_ == 2 && blocks * streams_ >= capacity);
-  if (channels_ == 2 && std::getenv("MIUPS_EXP_STEREO_EXT")) {  // experiment switch (profiles/)
+  if (channels_ == 2 && exp_.stereoExt) {  // experiment switch (profiles/)
     whole = false;
   }
   cg_ = whole ? channels_ : 1;
@@ -1043,10 +1077,10 @@ void Engine::PickChannelGroup(std::size_t blocks) {
   const std::size_t units = blocks * static_cast<std::size_t>(streams_) * channels_;
   // the split form (K = 32768 as two halves) divides by half transforms: 2P pieces per channel-block; the parked-input
   // experiment shares state between the two halves of a phase and keeps the plain form
-  const bool splitOk = filter_->fusedSplit() && g.log2k == 15 && std::getenv("MIUPS_EXP_PARK") == nullptr;
+  const bool splitOk = filter_->fusedSplit() && g.log2k == 15 && !exp_.park;
   const int pieces = filter_->fusedSplit() ? 2 * g.P : g.P;
   if ((splitOk || (!filter_->fusedSplit() && g.log2k >= kPartsMinLog2K && g.log2k <= 14)) && !narrow && !filter_->fusedR32() &&
-      smallCallSplit_ && std::getenv("MIUPS_EXP_NO_PHASE_PARTS") == nullptr) {  // experiment switch (profiles/)
+      smallCallSplit_ && !exp_.noPhaseParts) {  // experiment switch (profiles/)
     for (int d = pieces; d >= 2; --d) {
       if (pieces % d == 0 && units * static_cast<std::size_t>(d) <= static_cast<std::size_t>(cuCount_)) {
         parts_ = d;
@@ -1102,10 +1136,10 @@ bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, s
   hipStream_t ist = static_cast<hipStream_t>(stream);
   const int rows = g.P * channels_;
   int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
-  if (quad && !split && rows >= 16 && std::getenv("MIUPS_EXP_NO_TILED_INTERLEAVE") == nullptr) {  // experiment switch
+  if (quad && !split && rows >= 16 && !exp_.noTiledInterleave) {  // experiment switch
     tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
-    if (const char *ti = std::getenv("MIUPS_EXP_TILE_TI")) {  // experiment switch (profiles/): tile width 16 / 32 / 64
-      tiledTi = std::atoi(ti);
+    if (exp_.tileTi > 0) {  // experiment switch (profiles/): tile width 16 / 32 / 64
+      tiledTi = exp_.tileTi;
     }
     const int per = 1024 / tiledTi;  // rows per 16-byte word of a 256-thread pass over the tile
     if (rows % per != 0 || rows / per > 8 || rows > 512) {
@@ -1121,7 +1155,7 @@ bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, s
       }
       return false;
     }
-  } else if (quad && (rows == 4 || rows == 8) && std::getenv("MIUPS_EXP_NO_ROWS_INTERLEAVE") == nullptr) {  // experiment switch
+  } else if (quad && (rows == 4 || rows == 8) && !exp_.noRowsInterleave) {  // experiment switch
     const int threads = 256, perWg = threads * (32 / rows);  // interleave_rows_kernel: kDepth = 32 / R
     const int wgsPerPair = (g.Bc + perWg - 1) / perWg;
     const dim3 grid(static_cast<unsigned>(np) * wgsPerPair);
@@ -1278,8 +1312,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     const std::size_t pairs = static_cast<std::size_t>(blocks) * streams_;
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
     std::size_t budget = static_cast<std::size_t>(1024) << 20;
-    if (const char *mb = std::getenv("MIUPS_EXP_CHUNK_MB")) {  // experiment switch (profiles/)
-      budget = static_cast<std::size_t>(std::max(1, std::atoi(mb))) << 20;
+    if (exp_.chunkMb > 0) {  // experiment switch (profiles/)
+      budget = static_cast<std::size_t>(exp_.chunkMb) << 20;
     }
     std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / perPair));
     if (chunk < pairs && chunk * groups_ > wgCapacity_) {
@@ -1296,13 +1330,13 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // and 5 lose 17-22 % with pipelined launches, config 3 gains 4 %; profiles/r02_b_pipelined_launches.txt).
     bool pipelined = false;
     const bool sharedCus = wgCapacity_ >= 4 * static_cast<std::size_t>(cuCount_);
-    const char *forcePipe = std::getenv("MIUPS_EXP_PIPELINE");  // experiment switch (profiles/): 0 = never, 1 = always
-    if (ext && (forcePipe ? forcePipe[0] == '1' : sharedCus)) {
+    // exp_.pipeline: experiment switch (profiles/): 0 = never, 1 = always, -1 = by shape
+    if (ext && (exp_.pipeline >= 0 ? exp_.pipeline == 1 : sharedCus)) {
       const std::size_t totalWgs = pairs * groups_;
       const std::size_t rounds = (totalWgs + wgCapacity_ - 1) / wgCapacity_;
       std::size_t chunkRounds = std::max<std::size_t>(1, rounds / 8);
-      if (const char *cr = std::getenv("MIUPS_EXP_CHUNK_ROUNDS")) {  // experiment switch (profiles/)
-        chunkRounds = static_cast<std::size_t>(std::max(1, std::atoi(cr)));
+      if (exp_.chunkRounds > 0) {  // experiment switch (profiles/)
+        chunkRounds = static_cast<std::size_t>(exp_.chunkRounds);
       }
       std::size_t c = std::max<std::size_t>(1, chunkRounds * wgCapacity_ / groups_);
       c = std::min(c, std::max<std::size_t>(1, (budget / 2) / perPair));
@@ -1332,7 +1366,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // bytes per 32 (measured: its two first passes were 36 % of the kernel, profiles/r02_d_*); from a split-planar
     // timeline the lanes read consecutive 8-byte words.
     const bool splitPlanar = split && g.Bc % 4 == 0 && g.hist_frames == g.Oc && g.Oc % 4 == 0 &&
-                             std::getenv("MIUPS_EXP_NO_SPLIT_PLANAR") == nullptr;  // experiment switch (profiles/)
+                             !exp_.noSplitPlanar;  // experiment switch (profiles/)
     if ((channels_ > 2 || splitPlanar) && channels_ <= kMaxPlanarChannels) {
       if (!PlanarizeInput(g, io, blocks, splitPlanar, st, &ioF, error)) {
         return false;
@@ -1342,7 +1376,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     ioF.phase_parts = parts_;
     ioF.split_planes = split ? 1 : 0;
     ioF.park = nullptr;
-    if (split && std::getenv("MIUPS_EXP_PARK") != nullptr) {  // experiment switch (profiles/r03_g_split_park.txt): measured 0.89x
+    if (split && exp_.park) {  // experiment switch (profiles/r03_g_split_park.txt): measured 0.89x
       // the second half transform of a phase takes its first-pass inputs from here (kernel_fused.h phase_inputs2_both)
       const std::size_t words = static_cast<std::size_t>(split_park_words(g.K / 64));  // T = (K/2) / 32 threads
       const std::size_t need = std::min<std::size_t>(chunk, pairs) * groups_ * words * sizeof(f4);
@@ -1409,7 +1443,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     }
   } else if (tiled_covers(g.log2k) && tabs->count[9] == 2 * static_cast<std::size_t>(g.P) * g.K &&
              static_cast<long long>(blocks) * streams_ * channels_ * g.P * 32 < (1ll << 31) &&
-             std::getenv("MIUPS_EXP_NO_TWO_LEVEL") == nullptr) {  // experiment switch (profiles/): the pass-per-launch form
+             !exp_.noTwoLevel) {  // experiment switch (profiles/): the pass-per-launch form
     // K = 2^15 .. 2^18 outside the fused kernels (the "2m" filters at 2x / 4x / 8x): two-level transforms with the
     // M2-point rows in LDS (device/kernels_tiled.h), frames by the fused path's interleave kernels
     cg_ = 1;
@@ -1420,8 +1454,8 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     const std::size_t perPair = static_cast<std::size_t>(channels_) * g.P * g.Bp * sizeof(float);  // staging planes
     const std::size_t perItem = static_cast<std::size_t>(2 + g.P) * g.K * sizeof(cf);              // A, X and the P rows of B
     std::size_t budget = static_cast<std::size_t>(1024) << 20;
-    if (const char *mb = std::getenv("MIUPS_EXP_TWO_LEVEL_BUDGET_MB")) {  // experiment switch (profiles/r03_q_two_level.txt)
-      budget = static_cast<std::size_t>(std::max(1, std::atoi(mb))) << 20;
+    if (exp_.twoLevelBudgetMb > 0) {  // experiment switch (profiles/r03_q_two_level.txt)
+      budget = static_cast<std::size_t>(exp_.twoLevelBudgetMb) << 20;
     }
     const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(pairs, budget / (perItem * channels_ + perPair)));
     if (!EnsureWork(chunk * channels_, error, false)) {
@@ -1450,7 +1484,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // 160 of 500 us per launch, profiles/r03_q_two_level.txt) -- one fp32 timeline per channel first, as for wide fused frames
     IoDesc ioL = io;
     if (channels_ >= 2 && channels_ <= kMaxPlanarChannels && g.S == 1 && g.hist_frames == g.Oc &&
-        std::getenv("MIUPS_EXP_TWO_LEVEL_NO_PLANAR") == nullptr) {  // experiment switch (profiles/)
+        !exp_.twoLevelNoPlanar) {  // experiment switch (profiles/)
       if (!PlanarizeInput(g, io, blocks, false, st, &ioL, error)) {
         return false;
       }
@@ -1458,7 +1492,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     for (std::size_t p0 = 0; p0 < pairs; p0 += chunk) {
       const std::size_t np = std::min<std::size_t>(chunk, pairs - p0);
       ClassMark(1, st, true);
-      if (!LaunchTiled(g, ioL, *tabs, work_[0], work_[1], work_[2], scratch_, static_cast<int>(p0 * channels_),
+      if (!LaunchTiled(exp_.twoLevelStoreForward ? 0 : 1, g, ioL, *tabs, work_[0], work_[1], work_[2], scratch_, static_cast<int>(p0 * channels_),
                        static_cast<int>(np * channels_), st, error)) {
         return false;
       }
@@ -1528,6 +1562,70 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
   return MarkDone(hipStream, tabs, error);
 }
 
+// ---- the rule the host paths rest on, and its audit ---------------------------------------------------------------------
+// "Never two in-flight asynchronous copies on host ranges that are not page-locked and may share a page" (DESIGN 4,
+// profiles/r03_r_multi_fault.txt: the runtime pins a pageable range per copy and the shared page goes with the first copy
+// to complete -- a GPU memory fault that aborts the process). HostCopyAudit sees every asynchronous host copy ProcessHost
+// issues, with the page span of its host range and whether that range is page-locked, and every host-side wait that
+// retires copies; a copy that breaks the rule bumps a process-wide counter (mi_debug_unsafe_host_copies) which the GPU
+// tests of the host paths require to stay 0 -- a test of the rule itself instead of reruns that hope to meet the fault.
+namespace {
+std::atomic<unsigned long long> g_unsafeHostCopies{0};
+constexpr std::uintptr_t kHostPage = 4096;
+
+struct PageSpan {
+  std::uintptr_t lo, hi;  // first and last page-aligned address touched
+  bool touches(const PageSpan &o) const { return lo <= o.hi && o.lo <= hi; }
+};
+PageSpan SpanOf(const void *p, std::size_t bytes) {
+  const std::uintptr_t a = reinterpret_cast<std::uintptr_t>(p);
+  return PageSpan{a & ~(kHostPage - 1), (a + (bytes ? bytes - 1 : 0)) & ~(kHostPage - 1)};
+}
+
+class HostCopyAudit {
+ public:
+  enum Dir { kIn = 0, kOut = 1 };
+  void Issue(Dir d, const void *host, std::size_t bytes, bool pageLocked) {
+    if (pageLocked || bytes == 0) {
+      return;
+    }
+    const PageSpan sp = SpanOf(host, bytes);
+    for (const auto &v : open_) {
+      for (const PageSpan &o : v) {
+        if (sp.touches(o)) {
+          g_unsafeHostCopies.fetch_add(1, std::memory_order_relaxed);
+        }
+      }
+    }
+    open_[d].push_back(sp);
+  }
+  void Retired(Dir d) { open_[d].clear(); }  // the host has waited for every copy of this direction issued so far
+  void RetiredAll() {
+    open_[0].clear();
+    open_[1].clear();
+  }
+
+ private:
+  std::vector<PageSpan> open_[2];
+};
+}  // namespace
+
+unsigned long long UnsafeHostCopies() { return g_unsafeHostCopies.load(std::memory_order_relaxed); }
+
+// Both ends of [p, p + bytes) lie in page-locked host memory (hipHostMalloc / hipHostRegister). The first byte alone is not
+// enough: a caller may have registered a shorter length, or hand in a view that runs past a pinned allocation.
+bool HostRangePageLocked(const void *p, std::size_t bytes) {
+  auto locked = [](const void *q) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return a.type == hipMemoryTypeHost;
+  };
+  return p && locked(p) && (bytes <= 1 || locked(static_cast<const char *>(p) + bytes - 1));
+}
+
 // Host buffers. The call is cut into consecutive sub-batches of blocks; sub-batch j's H2D copy, its kernels and its D2H
 // copy run on three streams, each gated by events, through two device slots per direction: while the kernels of j run,
 // j+1 is being copied in and j-1 copied out. (A block depends on earlier blocks only through the input history, which
@@ -1576,8 +1674,8 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
   }
   // sub-batch size: up to 8 per call, but never so small that a launch cannot fill the chip
   std::size_t nsub = std::min<std::size_t>(8, blocks);
-  if (const char *v = std::getenv("MIUPS_EXP_HOST_SUBBATCHES")) {  // experiment switch (profiles/)
-    nsub = std::min<std::size_t>(blocks, static_cast<std::size_t>(std::max(1, std::atoi(v))));
+  if (exp_.hostSubBatches > 0) {  // experiment switch (profiles/)
+    nsub = std::min<std::size_t>(blocks, static_cast<std::size_t>(exp_.hostSubBatches));
   }
   const std::size_t minBlocks = std::max<std::size_t>(1, (static_cast<std::size_t>(cuCount_) + streams_ * channels_ - 1) /
                                                              (static_cast<std::size_t>(streams_) * channels_));
@@ -1613,43 +1711,70 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
       }
     }
   } pinIn, pinOut;
-  bool serialCopies = false;
-  if (streams_ > 1 || nsub > 1) {
-    auto pageLocked = [](const void *p) {
-      hipPointerAttribute_t a;
-      if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+  // EVERY exit that is not the successful one -- each MI_HIP below returns at once -- first waits for the three streams:
+  // copies of earlier sub-batches may still be in flight on h2d / d2h, and the pins above must not be released (nor the
+  // caller handed back a buffer it may free) under a running DMA: that is the very fault the pins exist to prevent.
+  // Declared after the pins, so it runs before them.
+  struct DrainOnFailure {
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    bool armed = false;
+    ~DrainOnFailure() {
+      if (armed) {
+        for (hipStream_t q : st) {
+          if (q) {
+            (void)hipStreamSynchronize(q);
+          }
+        }
         (void)hipGetLastError();
-        return false;
       }
-      return a.type == hipMemoryTypeHost;
-    };
-    const std::size_t inExtent = (static_cast<std::size_t>(streams_) - 1) * inStride + blocks * inBlockHost -
-                                 (pitchedIn ? inFramePitch - inFrame : 0);
-    const std::size_t outExtent = (static_cast<std::size_t>(streams_) - 1) * outStride + blocks * outBlockHost -
-                                  (pitchedOut ? outFramePitch - outFrame : 0);
-    if (!packIn && !pageLocked(hIn)) {
+    }
+  } drain;
+  HostCopyAudit audit;
+  bool serialCopies = false;
+  bool lockedIn = false, lockedOut = false;  // the caller's ranges are page-locked for the whole call (theirs or ours)
+  const std::size_t inExtent = (static_cast<std::size_t>(streams_) - 1) * inStride + blocks * inBlockHost -
+                               (pitchedIn ? inFramePitch - inFrame : 0);
+  const std::size_t outExtent = (static_cast<std::size_t>(streams_) - 1) * outStride + blocks * outBlockHost -
+                                (pitchedOut ? outFramePitch - outFrame : 0);
+  bool waitBetween = false;  // single copy in, single copy out (below): wait for the first before issuing the second
+  if (streams_ > 1 || nsub > 1) {
+    lockedIn = packIn || HostRangePageLocked(hIn, inExtent);
+    lockedOut = packOut || HostRangePageLocked(hOut, outExtent);
+    if (!lockedIn) {
       if (hipHostRegister(const_cast<void *>(hIn), inExtent, hipHostRegisterDefault) == hipSuccess) {
         pinIn.p = const_cast<void *>(hIn);
+        lockedIn = true;
       } else {
         (void)hipGetLastError();
         serialCopies = true;
       }
     }
-    if (!packOut && !pageLocked(hOut)) {
+    if (!lockedOut) {
       if (hipHostRegister(hOut, outExtent, hipHostRegisterDefault) == hipSuccess) {
         pinOut.p = hOut;
+        lockedOut = true;
       } else {
         (void)hipGetLastError();
         serialCopies = true;
       }
     }
+  } else if (!packIn && !packOut && SpanOf(hIn, inExtent).touches(SpanOf(hOut, outExtent))) {
+    // One copy in and one copy out (the reference's call shape, mi_ups_process_block): the pair itself is two copies, and
+    // heap neighbours share a page. Only then ask the runtime (two attribute queries stay off the 69 us path otherwise);
+    // unless both ends are page-locked the copy in is waited for before the copy out is issued.
+    lockedIn = HostRangePageLocked(hIn, inExtent);
+    lockedOut = HostRangePageLocked(hOut, outExtent);
+    waitBetween = !(lockedIn && lockedOut);
   }
   hipStream_t own = static_cast<hipStream_t>(own_), h2d = static_cast<hipStream_t>(h2d_), d2h = static_cast<hipStream_t>(d2h_);
+  drain.st[0] = h2d;
+  drain.st[1] = own;
+  drain.st[2] = d2h;
+  drain.armed = true;
   // One sub-batch (the reference's own call shape: one block per call) has nothing to overlap: copy in, kernels and copy
   // out follow each other on the engine's stream, without the three cross-stream events of the pipelined form
   // (mi_ups_process_block p50 132 -> see profiles/r03_n_step_overhead.txt).
-  const bool oneStream = nsub == 1 && hostOneStream_ &&
-                         std::getenv("MIUPS_EXP_HOST_THREE_STREAMS") == nullptr;  // experiment switch (profiles/)
+  const bool oneStream = nsub == 1 && hostOneStream_ && !exp_.hostThreeStreams;  // experiment switch (profiles/)
   if (oneStream) {
     h2d = d2h = own;
   }
@@ -1678,17 +1803,29 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
         }
         MI_HIP(hipMemcpy(static_cast<char *>(stageIn_[slot]) + s * inRow, hostRows.data(), rows * inFrame, hipMemcpyHostToDevice));
       } else if (pitchedIn) {
-        MI_HIP(hipMemcpy2DAsync(static_cast<char *>(stageIn_[slot]) + s * inRow, inFrame,
-                                static_cast<const char *>(hIn) + s * inStride + b0 * inBlockHost, inFramePitch, inFrame,
+        const char *src = static_cast<const char *>(hIn) + s * inStride + b0 * inBlockHost;
+        audit.Issue(HostCopyAudit::kIn, src, nb * inBlockHost - (inFramePitch - inFrame), lockedIn);
+        MI_HIP(hipMemcpy2DAsync(static_cast<char *>(stageIn_[slot]) + s * inRow, inFrame, src, inFramePitch, inFrame,
                                 nb * static_cast<std::size_t>(g.n_in), hipMemcpyHostToDevice, h2d));
       } else {
-        MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow,
-                              static_cast<const char *>(hIn) + s * inStride + b0 * inBlock, nb * inBlock,
-                              hipMemcpyHostToDevice, h2d));
+        const char *src = static_cast<const char *>(hIn) + s * inStride + b0 * inBlock;
+        audit.Issue(HostCopyAudit::kIn, src, nb * inBlock, lockedIn);
+        MI_HIP(hipMemcpyAsync(static_cast<char *>(stageIn_[slot]) + s * inRow, src, nb * inBlock, hipMemcpyHostToDevice, h2d));
       }
-      if (serialCopies && !packIn) {
+      if ((serialCopies || waitBetween) && !packIn) {
         MI_HIP(hipStreamSynchronize(h2d));
+        audit.Retired(HostCopyAudit::kIn);
+        if (oneStream) {
+          audit.RetiredAll();  // one stream: everything issued so far has completed
+        }
       }
+    }
+    if (failAtSubBatch_ == static_cast<int>(j)) {  // test hook (mi_debug_fail_host_call_at): as if the runtime had refused a call
+      failAtSubBatch_ = -1;
+      if (error) {
+        *error = "host copy failed (injected by test hook)";
+      }
+      return false;
     }
     if (!oneStream) {
       MI_HIP(hipEventRecord(evIn, h2d));
@@ -1698,10 +1835,7 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
       MI_HIP(hipStreamWaitEvent(own, evOut, 0));  // the output of j-2 has left this output slot
     }
     if (!ProcessDevice(stageIn_[slot], inRow, stageOut_[slot], outRow, nb, own_, error)) {
-      (void)hipStreamSynchronize(h2d);
-      (void)hipStreamSynchronize(own);
-      (void)hipStreamSynchronize(d2h);
-      return false;
+      return false;  // `drain` waits for the copies in flight before the pins go
     }
     if (!oneStream) {
       MI_HIP(hipEventRecord(evRun, own));
@@ -1725,16 +1859,22 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
           std::memcpy(dst + f * outFramePitch, hostRows.data() + f * outFrame, outFrame);
         }
       } else if (pitchedOut) {
-        MI_HIP(hipMemcpy2DAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlockHost, outFramePitch,
-                                static_cast<const char *>(stageOut_[slot]) + s * outRow, outFrame, outFrame,
+        char *dst = static_cast<char *>(hOut) + s * outStride + b0 * outBlockHost;
+        audit.Issue(HostCopyAudit::kOut, dst, nb * outBlockHost - (outFramePitch - outFrame), lockedOut);
+        MI_HIP(hipMemcpy2DAsync(dst, outFramePitch, static_cast<const char *>(stageOut_[slot]) + s * outRow, outFrame, outFrame,
                                 nb * static_cast<std::size_t>(g.B), hipMemcpyDeviceToHost, d2h));
       } else {
-        MI_HIP(hipMemcpyAsync(static_cast<char *>(hOut) + s * outStride + b0 * outBlock,
-                              static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock,
-                              hipMemcpyDeviceToHost, d2h));
+        char *dst = static_cast<char *>(hOut) + s * outStride + b0 * outBlock;
+        audit.Issue(HostCopyAudit::kOut, dst, nb * outBlock, lockedOut);
+        MI_HIP(hipMemcpyAsync(dst, static_cast<const char *>(stageOut_[slot]) + s * outRow, nb * outBlock, hipMemcpyDeviceToHost,
+                              d2h));
       }
       if (serialCopies && !packOut) {
         MI_HIP(hipStreamSynchronize(d2h));
+        audit.Retired(HostCopyAudit::kOut);
+        if (oneStream) {
+          audit.RetiredAll();
+        }
       }
     }
     if (!oneStream) {
@@ -1745,6 +1885,7 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
     MI_HIP(hipStreamSynchronize(d2h));
   }
   MI_HIP(hipStreamSynchronize(own));
+  drain.armed = false;  // everything has completed: nothing to wait for
   return true;
 }
 

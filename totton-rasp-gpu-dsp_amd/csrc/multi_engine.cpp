@@ -319,22 +319,14 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
                               blocks * static_cast<std::size_t>(g.n_in) * channels_ * pcm_bytes(inFmt_);
   const std::size_t outBytes = (static_cast<std::size_t>(streams_) - 1) * outStride +
                                blocks * static_cast<std::size_t>(g.B) * channels_ * pcm_bytes(outFmt_);
-  auto pageLocked = [](const void *p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    return a.type == hipMemoryTypeHost;
-  };
   (void)hipSetDevice(slots_[0]->device);
   bool regIn = false, regOut = false, serial = false;
   if (slots_.size() > 1) {
-    if (!pageLocked(hIn)) {
+    if (!HostRangePageLocked(hIn, inBytes)) {  // both ends of the extent, not the first byte alone
       regIn = hipHostRegister(const_cast<void *>(hIn), inBytes, hipHostRegisterPortable) == hipSuccess;
       serial = !regIn;
     }
-    if (!pageLocked(hOut)) {
+    if (!HostRangePageLocked(hOut, outBytes)) {
       regOut = hipHostRegister(hOut, outBytes, hipHostRegisterPortable) == hipSuccess;
       serial = serial || !regOut;
     }
@@ -352,6 +344,9 @@ bool MultiEngine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut,
   }
   cvJob_.notify_all();
   std::unique_lock<std::mutex> lock(mu_);
+  // pending_ == 0: every worker has RETURNED from its engine's ProcessHost, failed ones included -- and that function never
+  // returns with a copy in flight (its failure exits drain the streams first, engine.hip DrainOnFailure), so the
+  // registrations below are released with no DMA running on them (tests/test_gpu_stream_host.py, injected failure).
   cvDone_.wait(lock, [&] { return pending_ == 0; });
   if (regIn) {
     (void)hipHostUnregister(const_cast<void *>(hIn));

@@ -74,6 +74,12 @@ class MultiEngine {
   bool fused() const;
   // test hook: the next SetEq fails while building slot `slot`'s tables
   void FailNextEqOnSlotForTest(int slot) { failEqSlot_ = slot; }
+  // test hook: slot `slot`'s next ProcessHost fails after the host-to-device copies of its sub-batch j
+  void FailHostCallAtForTest(int slot, int j) {
+    if (slot >= 0 && slot < slots() && slots_[static_cast<std::size_t>(slot)]->engine) {
+      slots_[static_cast<std::size_t>(slot)]->engine->FailHostCallAtForTest(j);
+    }
+  }
   const std::string &workerAffinity(int slot) const { return slots_[static_cast<std::size_t>(slot)]->cpus; }
 
  private:
