@@ -55,6 +55,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: 64 FLOP/clk/SIMD, i.e. packed v_pk_fma_f32 on every issue slot
+FP32_SCALAR_ISSUE_PEAK_TF = FP32_VECTOR_PEAK_TF / 2  # one non-packed v_fma_f32 per issue slot: what scalar fp32 code can reach
 
 CONFIGS = {
     # id: (filter file, streams per GPU, channels, blocks per channel, description)   [BASELINE.md section 4]
@@ -128,6 +130,19 @@ def algorithmic_bytes(cfg: dict, units: int) -> float:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines --
+def model_flops(cfg: dict, units: int) -> dict:
+    """The arithmetic one launch does by the textbook count (what the path computes, whatever the kernel's instruction mix):
+    per channel-block (1 + P) complex transforms of K = N/(2P) points at 5 K log2 K, plus the spectral stage on K/2 mirror
+    pairs -- the real-FFT untangle once (14 flops: two complex adds, one complex multiply) and per phase two complex
+    products, two sums, the conj(W) multiply and the re-tangle (26 flops). P = L when L | N, else 1."""
+    n, L = cfg["fft_size"], max(1, cfg["upsample_factor"])
+    P = L if n % L == 0 else 1
+    K = n // P // 2
+    fft = (1 + P) * 5.0 * K * np.log2(K)
+    spectral = (K / 2.0) * (14.0 + 26.0 * P)
+    return {"P": P, "K": K, "transform": units * fft, "spectral": units * spectral, "total": units * (fft + spectral)}
+
+
 def host_cores() -> int:
     """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when one is set."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -399,7 +414,18 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
             "kernel_ms_min": round(kstat["min"], 5), "kernel_launches_timed": kstat["count"],
             "timed_every_nth_launch": getattr(w, "timing_every", 1),
             "algorithmic_bytes_per_launch": int(bytes_launch)}
-    key = (str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks") if w.config_id in CONFIGS else ""
+    # the roof that actually binds: fp32 vector arithmetic. Model flops per launch over the same kernel time.
+    mf = model_flops(w.cfg, w.units)
+    tf = mf["total"] / (kstat["avg"] * 1e-3) / 1e12 if kstat["avg"] > 0 else 0.0
+    roof["compute"] = {"bound": "fp32 vector (VALU)", "model_flops_per_launch": int(mf["total"]),
+                       "model": "units*((1+P)*5*K*log2(K) + (K/2)*(14+26*P)), K = N/(2P) = %d, P = %d" % (mf["K"], mf["P"]),
+                       "achieved": round(tf, 2), "unit": "TFLOP/s", "peak": FP32_VECTOR_PEAK_TF,
+                       "frac": round(tf / FP32_VECTOR_PEAK_TF, 4),
+                       "frac_of_scalar_issue_peak": round(tf / FP32_SCALAR_ISSUE_PEAK_TF, 4),
+                       "note": "157.3 TF needs packed v_pk_fma_f32 on every issue slot; scalar fp32 code (what measured fastest "
+                               "here, profiles/r02_b_packed_math.txt) tops out at half of it, and an FFT butterfly is ~40 % FMA"}
+    key = ((str(w.config_id) if w.blocks == CONFIGS[w.config_id][3] else f"{w.config_id}_{w.blocks}blocks")
+           if w.config_id in CONFIGS else getattr(w, "traffic_key", ""))
     rec = (traffic or {}).get(key)
     if rec and (rec["streams"], rec["channels"], rec["blocks"]) == (w.streams, w.channels, w.blocks):
         roof["traffic"] = int(rec["bytes"])
@@ -410,6 +436,7 @@ def summary(w: Workload, steps, elapsed, kstat, world=1, traffic=None) -> dict:
             # (profiles/r02_a_ubench_valu_lds_rates.txt), so this share of every wave's lifetime is VALU issue alone
             iv = dict(rec["issue"])
             iv["valu_issue_share_of_wave_clocks"] = round(iv["valu_insts_per_wave"] * 4.94 / iv["wave_clocks"], 3)
+            roof["compute"]["valu_busy_share"] = iv["valu_issue_share_of_wave_clocks"]
             iv["what"] = ("SQ counters of the same kernel, per launch (separate --pmc passes): the transform is VALU-issue / "
                           "LDS-write bound with its memory phases not overlapped (one workgroup owns the CU), not HBM-bound")
             roof["issue_view"] = iv
@@ -421,7 +448,8 @@ def config_block(w: Workload) -> dict:
     return {"workload": name, "filter": w.fname, "taps": w.cfg["taps"],
             "fft_size": w.cfg["fft_size"], "block_size": w.cfg["block_size"], "upsample_factor": w.cfg["upsample_factor"],
             "streams_per_gpu": w.streams, "channels": w.channels, "blocks_per_channel": w.blocks,
-            "pcm": "s32 interleaved in/out", "eq": bool(w.use_eq), "kernel_path": w.eng.path}
+            "pcm": "s32 interleaved in/out", "eq": bool(w.use_eq), "kernel_path": w.eng.path,
+            "coop_frames": bool(w.eng.last_coop_frames)}
 
 
 def end_to_end(ups, w: Workload, seconds=2.0) -> dict:
@@ -500,7 +528,35 @@ def process_block_latency(ups, device, filter_path, calls=1000) -> dict:
             "what": "mi_ups_process_block, one channel-block per call (host float in/out, blocking), headline filter"}
 
 
-def filters_2m(ups, hip, device, args, ceiling) -> list:
+def rows_8x_80k(ups, hip, device, args, ceiling, traffic, only=None) -> list:
+    """north_star: "Msamples/s for 80 k-tap 2x/4x/8x/16x". The 8x 80k-tap filter (K = 8192: 64 KiB of LDS, TWO workgroups
+    resident per CU) at the headline's stereo shape and at configs[4]'s 32-channel shape. Besides completing the ratio list
+    these rows are the evidence for DESIGN 11.1: what a second resident workgroup buys over K = 16384 (one per CU)."""
+    rows = []
+    for cid, channels, blocks in ((8, 2, 256), (9, 32, 64)):
+        key = f"8x80k_{channels}ch"
+        if only and only != key:
+            continue
+        wl = Workload(ups, hip, device, cid, 0, custom=(ROOT / "data" / "coefficients" / "filter_48k_8x_80000_min_phase.json", 1,
+                                                       channels, blocks, f"48k->384k 8x {channels}ch, 80k-tap min-phase (K = 8192)"))
+        wl.traffic_key = key
+        if args.prime_seconds > 0:
+            wl.prime(args.prime_seconds)
+        _, el, ks = wl.run(args.steps, args.warmup)
+        sm = summary(wl, args.steps, el, ks, 1, traffic)
+        if ceiling:
+            sm["roofline"]["frac_of_copy_ceiling"] = round(sm["roofline"]["achieved"] / ceiling, 5)
+        pk = wl.per_kernel_ms()
+        row = {"config": config_block(wl), "value": sm["value"], "unit": "Msamples/s", "ms_per_step": sm["ms_per_step"],
+               "roofline": sm["roofline"], "output_check": wl.check_output(), "per_kernel_ms": pk}
+        if pk.get("transform"):
+            row["transform_only_frac"] = round(algorithmic_bytes(wl.cfg, wl.units) / (pk["transform"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        rows.append(row)
+        wl.close()
+    return rows
+
+
+def filters_2m(ups, hip, device, args, ceiling, traffic=None, only=None) -> list:
     import tempfile
 
     sys.path.insert(0, str(ROOT / "totton-rasp-gpu-dsp_amd"))
@@ -512,11 +568,16 @@ def filters_2m(ups, hip, device, args, ceiling) -> list:
             h = fd.design(640_000, ratio, "48k", "linear")
             path = fd.export(h, Path(tmp), fd.base_name("48k", ratio, 640_000, "linear"), ratio)
             wl = Workload(ups, hip, device, cid, 0, custom=(path, 1, 8, 16, f"48k {ratio}x linear 640k-tap ('2m'), 8ch"))
+            wl.traffic_key = f"2m_{ratio}x"
+            if only and only != wl.traffic_key:
+                wl.close()
+                continue
             if args.prime_seconds > 0:
                 wl.prime(args.prime_seconds)
             _, el, ks = wl.run(max(5, args.steps // 4), 2)
-            sm = summary(wl, max(5, args.steps // 4), el, ks, 1, None)
-            sm["roofline"]["frac_of_copy_ceiling"] = round(sm["roofline"]["achieved"] / ceiling, 5)
+            sm = summary(wl, max(5, args.steps // 4), el, ks, 1, traffic)
+            if ceiling:
+                sm["roofline"]["frac_of_copy_ceiling"] = round(sm["roofline"]["achieved"] / ceiling, 5)
             rows.append({"config": config_block(wl), "value": sm["value"], "unit": "Msamples/s", "ms_per_step": sm["ms_per_step"],
                          "roofline": sm["roofline"], "two_level": bool(wl.eng.last_two_level), "output_check": wl.check_output(),
                          "per_kernel_ms": wl.per_kernel_ms()})
@@ -693,6 +754,8 @@ def main() -> int:
                     help="untimed run of the same call before the W warmup steps, so that the K timed steps see the device at "
                          "its running clocks (0 = off; variants.cold_start is the same K steps without it)")
     ap.add_argument("--eq", action="store_true", help="fold the 10-band EQ profile into the headline filter")
+    ap.add_argument("--row", default="", help="run ONE extra row instead of a config (for rocprofv3 passes): 2m_8x, 2m_2x, "
+                                              "8x80k_2ch, 8x80k_32ch")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: synthetic per-rank time (CPU tests)")
     args = ap.parse_args()
 
@@ -719,6 +782,21 @@ def main() -> int:
             print(f"bench.py: {world} ranks requested but only {ndev} HIP device(s) are visible; ranks are never "
                   "stacked on one GPU", file=sys.stderr)
             return 3
+    if args.row:
+        # one extra row alone (what the rocprofv3 kernel-trace / PMC passes of scripts/gpu_r04_measure.sh run)
+        if args.dry_run or world != 1:
+            print("bench.py: --row needs one real GPU", file=sys.stderr)
+            return 2
+        hip = Hip()
+        hip.check(hip.lib.hipSetDevice(0), "hipSetDevice")
+        try:
+            traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        except (OSError, ValueError):
+            traffic = {}
+        fn = filters_2m if args.row.startswith("2m_") else rows_8x_80k
+        rows = fn(ups, hip, 0, args, 0.0, traffic, only=args.row)
+        print(json.dumps({"row": args.row, "rows": rows}), flush=True)
+        return 0 if rows else 2
     fname, streams, channels, blocks, desc = CONFIGS[args.config]
     streams = args.streams or streams
     blocks = args.blocks or blocks
@@ -850,15 +928,20 @@ def run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, 
             _, el, ks = wc.run(args.steps, args.warmup)
             s = summary(wc, args.steps, el, ks, 1, traffic)
             s["roofline"]["frac_of_copy_ceiling"] = round(s["roofline"]["achieved"] / head["roofline"]["copy_ceiling_GBps"], 5)
+            pk = wc.per_kernel_ms()
             rows.append({"id": cid, "config": config_block(wc), "value": s["value"], "unit": "Msamples/s",
                          "ms_per_step": s["ms_per_step"], "roofline": s["roofline"], "output_check": wc.check_output(),
-                         "per_kernel_ms": wc.per_kernel_ms()})
+                         "per_kernel_ms": pk})
+            if pk.get("transform"):  # the transform kernel alone against the same algorithmic bytes (DESIGN 11.1's yardstick)
+                rows[-1]["transform_only_frac"] = round(
+                    algorithmic_bytes(wc.cfg, wc.units) / (pk["transform"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if wc is not w:
                 wc.close()
         extras["configs"] = rows
         # the 640 001-tap "2m" filters the selector prefers when present (alsa_filter_selector.cpp:74-96): transforms of
         # 2^16 / 2^18 points, past the fused kernels -- the two-level path. Designed here by the repo's generator.
-        extras["filters_2m"] = filters_2m(ups, hip, device, args, head["roofline"]["copy_ceiling_GBps"])
+        extras["filters_2m"] = filters_2m(ups, hip, device, args, head["roofline"]["copy_ceiling_GBps"], traffic)
+        extras["filters_8x_80k"] = rows_8x_80k(ups, hip, device, args, head["roofline"]["copy_ceiling_GBps"], traffic)
         extras["per_kernel_ms"] = ("roofline.kernel_ms_* = one hipEvent pair around all kernels of a call; configs[].per_kernel_ms = "
                                    "untimed extra steps with one event pair per launch (planarize / transform / frames / history; "
                                    "launches that overlap on two streams add up to more than the call); rocprofv3 --kernel-trace "
@@ -908,8 +991,12 @@ def run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, 
     if not args.dry_run:
         result["output_check"] = checked
         result["priming"] = {"seconds": args.prime_seconds, "calls": primed,
-                             "what": "untimed run of the headline call before the W warmup steps (device clocks); "
-                                     "0 disables, variants.cold_start is the measurement without it"}
+                             "headline_is": "primed" if args.prime_seconds > 0 else "cold",
+                             "what": "`value` is the PRIMED measurement: an untimed run of the headline call for `seconds` comes "
+                                     "before the W warmup + K timed steps (a device that has just been idle runs its first "
+                                     "milliseconds at lower clocks and K = 20 calls of 0.13 ms end before they have risen). The "
+                                     "literal contract -- W + K steps on the just-idle device, nothing before -- is "
+                                     "variants.cold_start; --prime-seconds 0 makes it the headline"}
         result["hip_runtimes_mapped"] = hip_runtimes_mapped()
     result.update(extras)
     if rank == 0:

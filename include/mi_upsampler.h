@@ -165,6 +165,11 @@ int mi_engine_last_phase_parts(const mi_engine *e);
  * 2x / 4x / 8x) ran the two-level transforms -- K = K1 x M2 with the M2-point rows in LDS, two HBM round trips per transform
  *  -- and 0 when it ran one launch per radix-16 pass (K outside 2^15 .. 2^18, or MIUPS_EXP_NO_TWO_LEVEL). */
 int mi_engine_last_two_level(const mi_engine *e);
+/* 1 when the latest call of a "fused" engine whose frames are wider than a workgroup's channel group (more than two
+ * channels) let the transform kernel's own workgroups assemble the PCM frames of finished (stream, block) pairs while the
+ * rest of the launch was still computing (cooperative frames); the frame pass behind the kernel then only
+ * takes the tiles nobody claimed. 0: the frame pass assembled every frame (MIUPS_EXP_NO_COOP_FRAMES, other shapes). */
+int mi_engine_last_coop_frames(const mi_engine *e);
 
 /* Process `blocks` consecutive blocks of every stream. d_in / d_out are DEVICE
  * pointers: stream s starts at base + s*stride bytes and holds interleaved

@@ -348,17 +348,67 @@ int main(int argc, char **argv) {
         ioF.park = park.data();
       }
       const bool quad = ioF.out_vec_ok && (outFmt == kF32 || outFmt == kS32) && (g.P * channels) % 4 == 0 && g.Bc % 4 == 0;
+      // EMU_COOP=1: cooperative frames, same rule as Engine::ProcessDevice (device/frame_tile.h). The emulation runs the
+      // workgroups of a launch one after the other, so a pair's last workgroup finds it complete and assembles up to its
+      // cap; later workgroups take older pairs' tiles; the frame pass behind the kernel takes the rest.
+      int coopTi = 0, coopEpt = 0;
+      std::vector<FrameSync> fsync;
+      if (std::getenv("EMU_COOP") && ext && !t.fusedSplit && parts == 0 && !t.fusedNarrow && !t.fusedR32 && quad &&
+          !std::getenv("EMU_NO_TILED_INTERLEAVE")) {
+        const int rows = g.P * channels, T = g.K / 32;
+        for (int ti : {64, 32, 16}) {
+          const int words = rows * (ti / 4), per = 1024 / ti;
+          const bool inKernel = T >= 64 && words % T == 0 && words / T >= 1 && words / T <= 8 &&
+                                64 + static_cast<long long>(rows) * (ti + 1) * 4 <= static_cast<long long>(g.K) * 8;
+          const bool framePass = rows >= 16 && rows % per == 0 && rows / per <= 8 && rows <= 512;
+          if (inKernel && framePass) {
+            coopTi = ti;
+            coopEpt = words / T;
+            break;
+          }
+        }
+        if (!coopTi) {
+          std::fprintf(stderr, "EMU_COOP: no tile width fits this shape\n");
+          return 2;
+        }
+        fsync.resize(chunk);
+        const int tiles = (g.Bc + coopTi - 1) / coopTi;
+        int cap = 2 * ((tiles + static_cast<int>(groups) - 1) / static_cast<int>(groups));
+        if (const char *c = std::getenv("EMU_COOP_CAP")) {
+          cap = std::atoi(c);
+        }
+        ioF.fsync = fsync.data();
+        ioF.ftile_ti = coopTi;
+        ioF.ftile_ept = coopEpt;
+        ioF.ftiles = tiles;
+        ioF.ftile_cap = std::max(2, (cap + 1) & ~1);
+      }
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);
         ioF.item0 = static_cast<int>(p0 * groups);
+        if (coopTi) {
+          std::fill(fsync.begin(), fsync.end(), FrameSync{});
+        }
         DispatchFused(g, ioF, t, np * groups * static_cast<unsigned>(parts ? parts : 1));
         if (!ext) {
           continue;
         }
+        if (coopTi) {  // how much of the frame work the transform kernel's workgroups took (stderr: the test reads it)
+          unsigned long long claimed = 0;
+          const unsigned tiles = static_cast<unsigned>(ioF.ftiles);
+          for (unsigned j = 0; j < np; ++j) {
+            claimed += std::min(fsync[j].next, tiles);
+          }
+          std::fprintf(stderr, "EMU_COOP: %llu of %llu tiles assembled inside the transform kernel\n", claimed,
+                       static_cast<unsigned long long>(np) * tiles);
+        }
         const int rows = g.P * channels;
-        int tiledTi = 0;  // same rule as the engine (its 256 threads are 32 here: EPT is 8x the engine's)
+        int tiledTi = 0;  // same rule as the engine
         if (quad && !t.fusedSplit && rows >= 16 && !std::getenv("EMU_NO_TILED_INTERLEAVE")) {
           tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
+          if (coopTi) {
+            tiledTi = coopTi;
+          }
           const int per = 1024 / tiledTi;
           if (rows % per != 0 || rows / per > 8 || rows > 512) {
             tiledTi = 0;

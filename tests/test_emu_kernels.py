@@ -484,3 +484,44 @@ def test_emulated_fused_and_staged_agree_on_real_geometry(emu, O, tmp_path):
         truth = O.truth_stream(x[:, c], h, L, 1, block).reshape(-1)
         assert rel_err(yf[:, c], truth) <= 1e-5
         assert rel_err(ys[:, c], truth) <= 1e-5
+
+
+@pytest.mark.parametrize("fft,taps,L,streams,channels,blocks,out_fmt,cap", [
+    (16384, 4097, 4, 1, 8, 4, "s32", None),   # K = 2048 (64 threads), 32 rows, 64-wide tiles, 8 words per thread
+    (16384, 4097, 4, 2, 8, 3, "f32", 4),      # two streams, odd pair count (chunks of 3 + 3 pairs), a small cap: most tiles
+                                              # are left to the frame pass
+    (32768, 8193, 4, 1, 8, 2, "s32", 1000),   # K = 4096 (128 threads), a cap nobody reaches: a pair's last workgroup takes all
+    (32768, 8449, 2, 1, 8, 2, "s32", None),   # K = 8192 (256 threads), 16 rows: one word per thread; Bc = 12160: partial last tile
+])
+def test_emulated_cooperative_frames(emu, O, make_filter, tmp_path, monkeypatch, fft, taps, L, streams, channels, blocks,
+                                     out_fmt, cap):
+    """Cooperative frames (device/frame_tile.h, EMU_COOP = the engine's default for these shapes): the transform kernel's
+    workgroups report their planes, assemble tiles of complete pairs up to their cap, and the frame pass behind the kernel
+    takes the tiles nobody claimed. Whatever the split between the two, every output byte must be the byte of the plain
+    route (frame pass alone) -- no tile lost, none written with stale planes -- and some tiles must really have been taken
+    inside the kernel. (The emulation runs a launch's workgroups one after the other: the ordering rules that matter on the
+    GPU -- planes visible before the count -- cannot fail here; the indexing, the claim arithmetic and the hand-over can.)"""
+    rng = np.random.default_rng(fft + L + channels + blocks)
+    h = (rng.standard_normal(taps) * 0.01).astype(np.float32)
+    block = fft - (taps - 1)
+    p = make_filter(h, fft, block, L)
+    nin = block // L
+    x = np.clip(rng.standard_normal((1, streams, blocks * nin, channels)) * 0.2, -1, 1).astype(np.float32)
+    plain = run_emu(emu, tmp_path, p, x.tobytes(), streams, channels, blocks, 1, "fused", "f32", out_fmt)
+    monkeypatch.setenv("EMU_COOP", "1")
+    if cap is not None:
+        monkeypatch.setenv("EMU_COOP_CAP", str(cap))
+    (tmp_path / "in.bin").write_bytes(x.tobytes())
+    r = subprocess.run([str(emu), str(p), "0", str(streams), str(channels), str(FMT["f32"]), str(FMT[out_fmt]), str(blocks), "1",
+                        str(tmp_path / "in.bin"), str(tmp_path / "out2.bin"), "fused"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    coop = (tmp_path / "out2.bin").read_bytes()
+    assert coop == plain
+    took = [tuple(int(v) for v in line.split()[1:4:2]) for line in r.stderr.splitlines() if line.startswith("EMU_COOP:")]
+    assert took and all(0 < a <= b for a, b in took), r.stderr[-500:]
+    if cap == 4:
+        assert all(a < b for a, b in took)       # the small cap leaves work for the frame pass
+    y = np.frombuffer(coop, np.float32) if out_fmt == "f32" else O.pcm_to_float(np.frombuffer(coop, np.uint8), out_fmt)
+    y = y.reshape(streams, blocks * block, channels)
+    truth = O.truth_stream(x[0, streams - 1, :, channels - 1], h, L, blocks, block).reshape(-1)
+    assert np.abs(y[streams - 1, :, channels - 1] - truth).max() <= 1e-5 * np.abs(truth).max() + 2.0**-31

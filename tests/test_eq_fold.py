@@ -129,7 +129,7 @@ def test_gpu_stream_with_eq_is_the_true_streaming_convolution(ups, O, gpu, key):
     assert np.abs(y - g[f"{key}_ideal"]).max() <= 1e-5 * scale + r["tail_l1"] * m["l1_ideal"] * m["max_x"]
     # the device-evaluated cascade is the yardstick of response_dev: the host figure is the same number
     _, rh = ups.eq_fold_host(h, fft, m["profile"], m["fs_out"])
-    assert r["response_dev"] == pytest.approx(rh["response_dev"], rel=1e-6, abs=1e-12)
+    assert r["response_dev"] == pytest.approx(rh["response_dev"], rel=1e-6, abs=1e-8)  # below that: fp64 noise of two FFT-size sums
     assert r["tail_l1"] == rh["tail_l1"]
 
 

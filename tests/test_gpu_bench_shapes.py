@@ -111,7 +111,7 @@ def synthetic_filter(make_filter, fft, taps, L, seed):
     return h, make_filter(h, fft, fft - (taps - 1), L, name=f"syn{fft}_{L}")
 
 
-def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2, want_parts=None):
+def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2, want_parts=None, want_coop=None):
     """`calls` consecutive device calls over the same buffers (the second starts from carried history); returns both
     outputs, int32 [call][stream][frame][channel]. want_parts: what Engine.last_phase_parts must say after a call."""
     eng = ups.Engine(filt, streams, channels, ups.PCM_S32, ups.PCM_S32)
@@ -124,6 +124,8 @@ def run_engine(ups, hip, filt, streams, channels, pcm, blocks, calls=2, want_par
         hip.sync()
         if want_parts is not None:
             assert eng.last_phase_parts == want_parts
+        if want_coop is not None:
+            assert eng.last_coop_frames == want_coop
         o = np.empty(out_stride * streams // 4, dtype="<i4")
         hip.d2h(o, d_out)
         outs.append(o.reshape(streams, -1, channels))
@@ -217,6 +219,39 @@ def test_small_calls_split_their_phases_over_workgroups(ups, O, hip, gpu, monkey
     np.testing.assert_array_equal(split, plain)
     x = np.concatenate(pcm, axis=1).astype(np.float64) / 2147483648.0
     y = np.concatenate(list(split), axis=1).astype(np.float64) / 2147483648.0
+    for s, c in ((0, 0), (streams - 1, channels - 1)):
+        want = np.clip(O.truth_stream(x[s, :, c], h, L, 2 * blocks, block).reshape(-1), -1.0, F32_HI)
+        assert np.abs(y[s, :, c] - want).max() <= 2.0 ** -31 + 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("fname,streams,channels,blocks", [
+    ("filter_48k_16x_80000_min_phase", 1, 8, 48),       # BASELINE configs[2] shape: K = 4096, 128 planes, several co-resident workgroups
+    ("filter_48k_8x_160000_linear_phase", 1, 32, 10),   # BASELINE configs[4] shape: K = 16384, 256 planes, one workgroup per CU
+    ("filter_48k_8x_80000_min_phase", 2, 32, 6),        # K = 8192, two streams
+    ("filter_48k_8x_80000_min_phase", 1, 2, 300),       # stereo that does not fill the chip: one channel per workgroup, 16 planes
+])
+def test_cooperative_frames_are_bit_identical_to_the_frame_pass(ups, O, hip, gpu, monkeypatch, fname, streams, channels, blocks):
+    """Cooperative frames (device/frame_tile.h; the default for frames wider than a workgroup's channel group): the transform
+    kernel's own workgroups assemble the PCM frames of finished pairs, the frame pass behind it takes what nobody claimed.
+    Same planes, same conversion: bit-identical to the frame pass alone (MIUPS_EXP_NO_COOP_FRAMES=1) over two calls, with a
+    cap nobody reaches (MIUPS_EXP_COOP_CAP: the pairs' last workgroups take everything) as with the default one, and against
+    fp64 truth."""
+    path = ROOT / "data" / "coefficients" / f"{fname}.json"
+    h, taps, fft, block, L = O.read_filter(path)
+    filt = ups.Filter(path, device=gpu)
+    nin = block // L
+    rng = np.random.default_rng(streams * 100 + channels * 10 + blocks)
+    pcm = [(np.clip(rng.standard_normal((streams, blocks * nin, channels)) * 0.05, -1, 1) * 2147483647).astype("<i4")
+           for _ in range(2)]
+    monkeypatch.setenv("MIUPS_EXP_NO_COOP_FRAMES", "1")
+    plain = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_coop=False)
+    monkeypatch.delenv("MIUPS_EXP_NO_COOP_FRAMES")
+    coop = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_coop=True)
+    np.testing.assert_array_equal(coop, plain)
+    monkeypatch.setenv("MIUPS_EXP_COOP_CAP", "100000")
+    np.testing.assert_array_equal(run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_coop=True), plain)
+    x = np.concatenate(pcm, axis=1).astype(np.float64) / 2147483648.0
+    y = np.concatenate(list(coop), axis=1).astype(np.float64) / 2147483648.0
     for s, c in ((0, 0), (streams - 1, channels - 1)):
         want = np.clip(O.truth_stream(x[s, :, c], h, L, 2 * blocks, block).reshape(-1), -1.0, F32_HI)
         assert np.abs(y[s, :, c] - want).max() <= 2.0 ** -31 + 1e-5 * np.abs(want).max()

@@ -105,6 +105,7 @@ def _load():
         "mi_ups_process_block": (C.c_long, [vp, f32p, sz, f32p, sz]),
         "mi_ups_reset": (i32, [vp]),
         "mi_ups_set_eq": (i32, [vp, cp, dbl]),
+        "mi_engine_last_coop_frames": (i32, [vp]),
         "mi_debug_unsafe_host_copies": (C.c_ulonglong, []),
         "mi_debug_fail_host_call_at": (None, [vp, i32]),
         "mi_debug_multi_fail_host_call_at": (None, [vp, i32, i32]),
@@ -236,6 +237,7 @@ EXPORTED_SYMBOLS = [
     "mi_fused_plan_radices", "mi_ups_eq_residual", "mi_ups_set_eq_limit", "mi_filter_eq_residual",
     "mi_filter_set_eq_limit", "mi_multi_eq_residual", "mi_multi_set_eq_limit", "mi_eq_fold_host",
     "mi_debug_unsafe_host_copies", "mi_debug_fail_host_call_at", "mi_debug_multi_fail_host_call_at",
+    "mi_engine_last_coop_frames",
 ]
 
 
@@ -460,6 +462,11 @@ class Engine:
     def last_two_level(self) -> bool:
         """True when the latest call of a staged engine ran the two-level transforms (K = 2^15 .. 2^18)."""
         return bool(lib.mi_engine_last_two_level(self._h))
+
+    @property
+    def last_coop_frames(self) -> bool:
+        """True when the latest call's transform kernel assembled frames itself (cooperative frames)."""
+        return bool(lib.mi_engine_last_coop_frames(self._h))
 
     def enable_kernel_timing(self, slots: int = 1, every: int = 1) -> None:
         """Ring of `slots` hipEvent pairs around the main kernel(s) of a process call; only every `every`-th call carries one."""

@@ -626,6 +626,8 @@ int mi_engine_set_kernel_timing_stride(mi_engine *e, int every) {
   return MI_OK;
 }
 
+int mi_engine_last_coop_frames(const mi_engine *e) { return (e && e->engine && e->engine->lastCoopFrames()) ? 1 : 0; }
+
 double mi_engine_last_kernel_ms(mi_engine *e) { return e ? e->engine->LastKernelMs() : -1.0; }
 
 int mi_engine_enable_class_timing(mi_engine *e, int on) {

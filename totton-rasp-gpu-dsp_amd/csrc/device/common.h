@@ -240,6 +240,15 @@ struct Geometry {
   int Bp;
 };
 
+// Cooperative frame assembly (device/frame_tile.h): one record per (stream, block) pair of a launch, zeroed before it. A
+// 128-byte line of its own: the counters of two pairs are never updated through two different L2s in one line.
+struct alignas(128) FrameSync {
+  unsigned done;      // workgroups of this pair whose planes are stored (complete at IoDesc::groups)
+  unsigned xcc_mask;  // OR of (1 << XCC_ID) of those workgroups: the pair is eligible only where this is ONE bit
+  unsigned next;      // first tile nobody has claimed; the frame pass behind the kernel assembles tiles >= next
+  unsigned pad[29];
+};
+
 // Where samples live for one batched call. Frames are interleaved:
 // sample(stream s, frame f, channel c) at
 //   base + s * stream_stride_bytes + (f * channels + c) * bytes(fmt)
@@ -283,6 +292,12 @@ struct IoDesc {
   f4 *park;
   // fused_parts_kernel: workgroups per work item (a divisor of P, >= 2); 0 elsewhere
   int phase_parts;
+  // cooperative frames (ext_epilogue, plain plane layout, device/frame_tile.h): null = off. [launch-local pair]
+  FrameSync *fsync;
+  int ftile_ti;    // tile width in kept samples: 64 / 32 / 16 (the frame pass behind the kernel uses the same)
+  int ftile_ept;   // sixteen-byte words per thread and tile inside the transform kernel: R * (ti / 4) / T, 1..8
+  int ftiles;      // tiles per pair
+  int ftile_cap;   // tiles one workgroup may assemble (about twice its share)
 };
 // smallest transform length (log2) that has a fused_parts_kernel
 constexpr int kPartsMinLog2K = 10;

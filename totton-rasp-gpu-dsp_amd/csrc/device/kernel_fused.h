@@ -42,6 +42,7 @@
 
 #include "common.h"
 #include "fft_radix.h"
+#include "frame_tile.h"
 #include "pcm.h"
 
 
@@ -2085,6 +2086,13 @@ struct FusedKernel {
     if constexpr (!SPLIT && !EXT) {  // the split form always leaves the frames to interleave_*_kernel (its own epilogue
                                      // measured no faster than the separate pass: profiles/r02_d_*)
       epilogue(g, io, s, c0, blk, scr, lds, tid);
+    }
+    if constexpr (!SPLIT && EXT && !PARTS && W == 2) {
+      // cooperative frames: this workgroup's planes are stored; say so, then assemble tiles of pairs that are complete
+      // (device/frame_tile.h). Workgroup-uniform branch; nothing here waits for another workgroup.
+      if (io.fsync != nullptr) {
+        coop_frames<T>(g, io, unit, reinterpret_cast<float *>(lds), tid);
+      }
     }
     MI_STAMP(129);
   }

@@ -429,6 +429,11 @@ MI_GLOBAL MI_ILV_VGPR_CAP void interleave_tiled_kernel(Geometry g, IoDesc io, co
     return;
   }
   const int k = static_cast<int>(MI_BID_X) - jb * tiles_per_pair;
+  // cooperative frames (device/frame_tile.h): the transform kernel's own workgroups have assembled the tiles below
+  // FrameSync::next of this pair (same tile width); this pass takes the rest
+  if (io.fsync != nullptr && static_cast<unsigned>(k) < io.fsync[jb].next) {
+    return;
+  }
   const int C = io.channels, P = g.P, R = P * C, Rq = R >> 2;
   const int i0 = k * TI;
   const int sb = sb0 + jb, s = sb / io.blocks, blk = sb - s * io.blocks;

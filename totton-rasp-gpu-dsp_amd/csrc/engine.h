@@ -126,7 +126,8 @@ bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBin
 struct ExpSwitches {
   bool stereoExt = false, park = false, noPhaseParts = false, noTiledInterleave = false, noRowsInterleave = false,
        noSplitPlanar = false, noTwoLevel = false, twoLevelNoPlanar = false, twoLevelStoreForward = false,
-       hostThreeStreams = false;
+       hostThreeStreams = false, noCoopFrames = false;
+  int coopCap = 0;
   int tileTi = 0, chunkMb = 0, chunkRounds = 0, twoLevelBudgetMb = 0, hostSubBatches = 0;
   int pipeline = -1;  // 0 = never, 1 = always, -1 = by shape
   static ExpSwitches FromEnvironment();
@@ -185,6 +186,8 @@ class Engine {
   int lastPhaseParts() const { return parts_; }
   // the latest staged call ran the two-level transforms (device/kernels_tiled.h) rather than one launch per pass
   bool lastTwoLevel() const { return lastTwoLevel_; }
+  // the latest fused call let the transform kernel's own workgroups assemble frames (cooperative frames)
+  bool lastCoopFrames() const { return lastCoop_; }
   void SetTimingStride(int every) { timingEvery_ = every < 1 ? 1 : every; }
   double LastKernelMs();
   // Per kernel class of the LATEST call: [0] planarize, [1] transform, [2] frame assembly (interleave_*), [3] history
@@ -206,7 +209,7 @@ class Engine {
   bool PlanarizeInput(const Geometry &g, const IoDesc &io, std::size_t blocks, bool splitPlanar, void *stream, IoDesc *ioF,
                       std::string *error);
   bool LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
-                    bool quad, void *stream, std::string *error);
+                    bool quad, void *stream, std::string *error, int forceTi = 0);
   bool EnsureStreams(std::string *error);
   void *TakeEvent();                       // hipEvent_t from the pool
   void Reap(bool all);                     // release table snapshots of finished calls
@@ -229,6 +232,9 @@ class Engine {
   std::size_t scratchBytes_ = 0;
   float *planar_ = nullptr;        // fused path, > 2 channels: per-channel fp32 timelines (planarize_kernel)
   std::size_t planarBytes_ = 0;
+  void *fsync_ = nullptr;          // cooperative frames: one FrameSync per (stream, block) pair of a launch (device/frame_tile.h)
+  std::size_t fsyncPairs_ = 0;
+  bool lastCoop_ = false;
   void *park_ = nullptr;           // split form: parked first-pass inputs of the second half transforms (IoDesc::park)
   std::size_t parkBytes_ = 0;
   void *hist_[2] = {nullptr, nullptr};

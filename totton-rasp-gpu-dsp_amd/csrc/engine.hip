@@ -723,6 +723,7 @@ Engine::~Engine() {
   (void)hipFree(scratch_);
   (void)hipFree(planar_);
   (void)hipFree(park_);
+  (void)hipFree(fsync_);
   for (void *e : eventPool_) {
     (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   }
@@ -765,6 +766,8 @@ ExpSwitches ExpSwitches::FromEnvironment() {
   x.twoLevelNoPlanar = on("MIUPS_EXP_TWO_LEVEL_NO_PLANAR");
   x.twoLevelStoreForward = on("MIUPS_EXP_TWO_LEVEL_STORE_FORWARD");
   x.hostThreeStreams = on("MIUPS_EXP_HOST_THREE_STREAMS");
+  x.noCoopFrames = on("MIUPS_EXP_NO_COOP_FRAMES");
+  x.coopCap = num("MIUPS_EXP_COOP_CAP");
   x.tileTi = num("MIUPS_EXP_TILE_TI");
   x.chunkMb = num("MIUPS_EXP_CHUNK_MB");
   x.chunkRounds = num("MIUPS_EXP_CHUNK_ROUNDS");
@@ -1132,7 +1135,7 @@ bool Engine::PlanarizeInput(const Geometry &g, const IoDesc &io, std::size_t blo
 
 // staging planes of pairs [p0, p0 + np) -> interleaved PCM frames (shared by the fused and the two-level paths)
 bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, std::size_t p0, std::size_t np, bool split,
-                          bool quad, void *stream, std::string *error) {
+                          bool quad, void *stream, std::string *error, int forceTi) {
   hipStream_t ist = static_cast<hipStream_t>(stream);
   const int rows = g.P * channels_;
   int tiledTi = 0;  // many planes, plain layout: the LDS-tiled form (kernels_generic.h), else the quad form
@@ -1140,6 +1143,9 @@ bool Engine::LaunchFrames(const Geometry &g, const IoDesc &ioF, float *planes, s
     tiledTi = rows <= 128 ? 64 : (rows <= 256 ? 32 : 16);
     if (exp_.tileTi > 0) {  // experiment switch (profiles/): tile width 16 / 32 / 64
       tiledTi = exp_.tileTi;
+    }
+    if (forceTi > 0) {  // cooperative frames: the tile width the transform kernel's workgroups used
+      tiledTi = forceTi;
     }
     const int per = 1024 / tiledTi;  // rows per 16-byte word of a 256-thread pass over the tile
     if (rows % per != 0 || rows / per > 8 || rows > 512) {
@@ -1303,6 +1309,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     MI_HIP(hipEventRecord(static_cast<hipEvent_t>(evStart_[slot]), st));
   }
   lastTwoLevel_ = false;
+  lastCoop_ = false;
   if (fused_) {
     // one workgroup per (stream, block, channel group); launches are chunked by whole (stream, block) pairs so that
     // the fp32 staging planes (channels * B floats per pair) stay bounded.
@@ -1328,8 +1335,34 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // Only where several workgroups share a CU (K <= 4096): a K = 16384 workgroup owns its CU's whole LDS and
     // register file, so an interleave workgroup that lands there keeps a transform workgroup out (measured: configs 4
     // and 5 lose 17-22 % with pipelined launches, config 3 gains 4 %; profiles/r02_b_pipelined_launches.txt).
+    io.out_vec_ok = (reinterpret_cast<std::uintptr_t>(dOut) % 16 == 0 && outStride % 16 == 0 &&
+                     (static_cast<std::size_t>(g.B) * channels_ * 4) % 16 == 0)
+                        ? 1
+                        : 0;
+    const bool quad = io.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 && g.Bc % 4 == 0;
+    // Cooperative frames (device/frame_tile.h): the transform kernel's own workgroups assemble the frames of
+    // pairs whose planes are complete while the rest of the launch computes; the frame pass behind the kernel takes what
+    // is left. Needs the LDS-tiled frame form with ONE tile width that suits both the transform kernel's T threads
+    // (1..8 sixteen-byte words per thread, the tile in the workgroup's own LDS) and the 256-thread frame pass.
+    int coopTi = 0, coopEpt = 0;
+    if (ext && !split && parts_ == 0 && !filter_->fusedNarrow() && !filter_->fusedR32() && quad && !exp_.noCoopFrames &&
+        !exp_.noTiledInterleave && exp_.pipeline != 1) {
+      const int rows = g.P * channels_, T = g.K / 32;
+      for (int ti : {64, 32, 16}) {
+        const int words = rows * (ti / 4), per = 1024 / ti;
+        const bool inKernel = T >= 64 && words % T == 0 && words / T >= 1 && words / T <= 8 &&
+                              64 + static_cast<long long>(rows) * (ti + 1) * 4 <= static_cast<long long>(g.K) * 8;
+        const bool framePass = rows >= 16 && rows % per == 0 && rows / per <= 8 && rows <= 512;
+        if (inKernel && framePass) {
+          coopTi = ti;
+          coopEpt = words / T;
+          break;
+        }
+      }
+    }
+    lastCoop_ = coopTi > 0;
     bool pipelined = false;
-    const bool sharedCus = wgCapacity_ >= 4 * static_cast<std::size_t>(cuCount_);
+    const bool sharedCus = wgCapacity_ >= 4 * static_cast<std::size_t>(cuCount_) && coopTi == 0;
     // exp_.pipeline: experiment switch (profiles/): 0 = never, 1 = always, -1 = by shape
     if (ext && (exp_.pipeline >= 0 ? exp_.pipeline == 1 : sharedCus)) {
       const std::size_t totalWgs = pairs * groups_;
@@ -1357,10 +1390,14 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     io.scratch = scratch_;
     io.cg = cg_;
     io.groups = groups_;
-    io.out_vec_ok = (reinterpret_cast<std::uintptr_t>(dOut) % 16 == 0 && outStride % 16 == 0 &&
-                     (static_cast<std::size_t>(g.B) * channels_ * 4) % 16 == 0)
-                        ? 1
-                        : 0;
+    if (coopTi && std::min<std::size_t>(chunk, pairs) > fsyncPairs_) {
+      Reap(true);
+      (void)hipFree(fsync_);
+      fsync_ = nullptr;
+      fsyncPairs_ = 0;
+      MI_HIP(hipMalloc(&fsync_, std::min<std::size_t>(chunk, pairs) * sizeof(FrameSync)));
+      fsyncPairs_ = std::min<std::size_t>(chunk, pairs);
+    }
     IoDesc ioF = io;  // what the fused kernel reads (io keeps the caller's buffers for the history carry)
     // The split form reads every second complex word per transform half: from interleaved stereo PCM that is 8 useful
     // bytes per 32 (measured: its two first passes were 36 % of the kernel, profiles/r02_d_*); from a split-planar
@@ -1390,8 +1427,19 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       ioF.park = static_cast<f4 *>(park_);
     }
-    const bool quad = ioF.out_vec_ok && (outFmt_ == kF32 || outFmt_ == kS32) && (g.P * channels_) % 4 == 0 &&
-                      g.Bc % 4 == 0;
+    ioF.fsync = nullptr;
+    if (coopTi) {
+      const int tiles = (g.Bc + coopTi - 1) / coopTi;
+      int cap = 2 * ((tiles + groups_ - 1) / groups_);
+      if (exp_.coopCap > 0) {  // experiment switch (profiles/r04_*)
+        cap = exp_.coopCap;
+      }
+      ioF.fsync = static_cast<FrameSync *>(fsync_);
+      ioF.ftile_ti = coopTi;
+      ioF.ftile_ept = coopEpt;
+      ioF.ftiles = tiles;
+      ioF.ftile_cap = std::max(2, (cap + 1) & ~1);
+    }
     hipStream_t aux = static_cast<hipStream_t>(aux_);
     std::size_t k = 0;
     bool usedHalf[2] = {false, false};
@@ -1405,6 +1453,9 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       ioF.item0 = static_cast<int>(p0 * groups_);
       ioF.scratch = planes;
+      if (ioF.fsync) {
+        MI_HIP(hipMemsetAsync(fsync_, 0, np * sizeof(FrameSync), st));
+      }
       ClassMark(1, st, true);
       if (!DispatchFused(g, ioF, tabs->fused(), split, filter_->fusedNarrow(), filter_->fusedR32(),
                          static_cast<unsigned>(np * groups_ * static_cast<std::size_t>(parts_ ? parts_ : 1)), st, error)) {
@@ -1422,7 +1473,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       }
       // staging planes of this chunk -> interleaved PCM frames
       ClassMark(2, ist, true);
-      if (!LaunchFrames(g, ioF, planes, p0, np, split, quad, ist, error)) {
+      if (!LaunchFrames(g, ioF, planes, p0, np, split, quad, ist, error, coopTi)) {
         return false;
       }
       ClassMark(2, ist, false);
