@@ -938,6 +938,18 @@ def run_rank(args, ups, ctl, rank, local_rank, world, fname, streams, channels, 
             if wc is not w:
                 wc.close()
         extras["configs"] = rows
+        # configs[2] as a LONG call (1024 blocks per channel: eight rounds of workgroups): where the transform kernel's own
+        # workgroups assemble the frames of finished pairs while the rest of the launch computes (cooperative frames,
+        # DESIGN 5.3b) -- the stated 256-block call is two rounds long and keeps the frame pass
+        wl = Workload(ups, hip, device, 3, rank, blocks=1024)
+        if args.prime_seconds > 0:
+            wl.prime(args.prime_seconds)
+        _, el, ks = wl.run(args.steps, args.warmup)
+        s = summary(wl, args.steps, el, ks, 1, traffic)
+        extras["config3_1024_blocks"] = {"config": config_block(wl), "value": s["value"], "unit": "Msamples/s",
+                                         "ms_per_step": s["ms_per_step"], "roofline": s["roofline"],
+                                         "output_check": wl.check_output(), "per_kernel_ms": wl.per_kernel_ms()}
+        wl.close()
         # the 640 001-tap "2m" filters the selector prefers when present (alsa_filter_selector.cpp:74-96): transforms of
         # 2^16 / 2^18 points, past the fused kernels -- the two-level path. Designed here by the repo's generator.
         extras["filters_2m"] = filters_2m(ups, hip, device, args, head["roofline"]["copy_ceiling_GBps"], traffic)

@@ -14,7 +14,10 @@ ROOT = Path(__file__).resolve().parents[1]
 PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r03_m"  # profiles/<PREFIX>_pmc_<tag>.txt
 SRC = ROOT / (sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r03m")
 TAGS = {"c2_256": ("2", 1, 2, 256), "c2_2048": ("2_2048blocks", 1, 2, 2048), "c3": ("3", 1, 8, 256), "c4": ("4", 32, 2, 32),
-        "c5": ("5", 1, 32, 64)}
+        "c5": ("5", 1, 32, 64),
+        # rows outside BASELINE's configs (bench.py --row): the 640k-tap filters through the two-level path, the 8x 80k-tap filter
+        "2m_8x": ("2m_8x", 1, 8, 16), "2m_2x": ("2m_2x", 1, 8, 16), "8x80k_2ch": ("8x80k_2ch", 1, 2, 256),
+        "8x80k_32ch": ("8x80k_32ch", 1, 32, 64)}
 
 
 def parse(path):
@@ -32,7 +35,13 @@ def parse(path):
 
 def main():
     res = {"_comment": __doc__.strip().replace("\n", " ")}
+    try:  # tags this visit did not measure keep their previous record
+        res.update({k: v for k, v in json.loads((ROOT / "profiles" / "traffic.json").read_text()).items() if k != "_comment"})
+    except (OSError, ValueError):
+        pass
     for tag, (key, streams, channels, blocks) in TAGS.items():
+        if not (SRC / f"pmc_{tag}.txt").exists():
+            continue
         k = parse(SRC / f"pmc_{tag}.txt")
         calls = k["miups::update_history_kernel"]["FETCH_SIZE"][1]  # one per bench step
         kernels, total = {}, 0.0

@@ -358,7 +358,7 @@ int main(int argc, char **argv) {
         const int rows = g.P * channels, T = g.K / 32;
         for (int ti : {64, 32, 16}) {
           const int words = rows * (ti / 4), per = 1024 / ti;
-          const bool inKernel = T >= 64 && words % T == 0 && words / T >= 1 && words / T <= 8 &&
+          const bool inKernel = T >= 64 && words % T == 0 && (words / T == 1 || words / T == 2 || words / T == 4 || words / T == 8) &&
                                 64 + static_cast<long long>(rows) * (ti + 1) * 4 <= static_cast<long long>(g.K) * 8;
           const bool framePass = rows >= 16 && rows % per == 0 && rows / per <= 8 && rows <= 512;
           if (inKernel && framePass) {
@@ -381,7 +381,7 @@ int main(int argc, char **argv) {
         ioF.ftile_ti = coopTi;
         ioF.ftile_ept = coopEpt;
         ioF.ftiles = tiles;
-        ioF.ftile_cap = std::max(2, (cap + 1) & ~1);
+        ioF.ftile_cap = std::max(1, cap);
       }
       for (unsigned p0 = 0; p0 < pairs; p0 += chunk) {
         const unsigned np = std::min(chunk, pairs - p0);

@@ -231,8 +231,9 @@ def test_small_calls_split_their_phases_over_workgroups(ups, O, hip, gpu, monkey
     ("filter_48k_8x_80000_min_phase", 1, 2, 300),       # stereo that does not fill the chip: one channel per workgroup, 16 planes
 ])
 def test_cooperative_frames_are_bit_identical_to_the_frame_pass(ups, O, hip, gpu, monkeypatch, fname, streams, channels, blocks):
-    """Cooperative frames (device/frame_tile.h; the default for frames wider than a workgroup's channel group): the transform
-    kernel's own workgroups assemble the PCM frames of finished pairs, the frame pass behind it takes what nobody claimed.
+    """Cooperative frames (device/frame_tile.h; taken by default where several workgroups share a CU and the launch is at
+    least four rounds long, forced here at every shape the kernels cover): the transform kernel's own workgroups assemble
+    the PCM frames of finished pairs, the frame pass behind it takes what nobody claimed.
     Same planes, same conversion: bit-identical to the frame pass alone (MIUPS_EXP_NO_COOP_FRAMES=1) over two calls, with a
     cap nobody reaches (MIUPS_EXP_COOP_CAP: the pairs' last workgroups take everything) as with the default one, and against
     fp64 truth."""
@@ -246,6 +247,7 @@ def test_cooperative_frames_are_bit_identical_to_the_frame_pass(ups, O, hip, gpu
     monkeypatch.setenv("MIUPS_EXP_NO_COOP_FRAMES", "1")
     plain = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_coop=False)
     monkeypatch.delenv("MIUPS_EXP_NO_COOP_FRAMES")
+    monkeypatch.setenv("MIUPS_EXP_COOP_FRAMES", "1")   # whatever the launch shape (the default takes it only where it pays)
     coop = run_engine(ups, hip, filt, streams, channels, pcm, blocks, want_coop=True)
     np.testing.assert_array_equal(coop, plain)
     monkeypatch.setenv("MIUPS_EXP_COOP_CAP", "100000")
@@ -255,3 +257,21 @@ def test_cooperative_frames_are_bit_identical_to_the_frame_pass(ups, O, hip, gpu
     for s, c in ((0, 0), (streams - 1, channels - 1)):
         want = np.clip(O.truth_stream(x[s, :, c], h, L, 2 * blocks, block).reshape(-1), -1.0, F32_HI)
         assert np.abs(y[s, :, c] - want).max() <= 2.0 ** -31 + 1e-5 * np.abs(want).max()
+
+
+def test_cooperative_frames_default_policy(ups, hip, gpu):
+    """The default takes cooperative frames only where they measured faster (profiles/r04_b_coop_frames.txt): K <= 4096 and
+    at least four full-chip rounds of workgroups. configs[2]'s shape at 512 blocks: yes; at its stated 256 blocks: no (the
+    two-stream pipelined route stays); K = 16384 (configs[4]): no."""
+    f16 = ups.Filter(ROOT / "data" / "coefficients" / "filter_48k_16x_80000_min_phase.json", device=gpu)
+    f8 = ups.Filter(ROOT / "data" / "coefficients" / "filter_48k_8x_160000_linear_phase.json", device=gpu)
+    for filt, channels, blocks, want in ((f16, 8, 512, True), (f16, 8, 256, False), (f8, 32, 64, False)):
+        eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+        d_in, d_out = hip.malloc(eng.in_bytes(blocks)), hip.malloc(eng.out_bytes(blocks))
+        hip.h2d(d_in, np.zeros(eng.in_bytes(blocks), dtype=np.uint8))
+        eng.process_device(d_in, d_out, blocks)
+        hip.sync()
+        assert eng.last_coop_frames == want, (channels, blocks)
+        hip.free(d_in)
+        hip.free(d_out)
+        eng.close()

@@ -100,8 +100,9 @@ def test_bench_configs_with_eq_as_benched(ups, O, gpu, fname, fs, channels, bloc
 @pytest.mark.gpu
 def test_staged_and_fused_paths_agree_at_full_size(ups, O, gpu, make_filter):
     """2x filter -> K = 32768: the split fused kernel (two 16384-point halves); 4x -> fused;
-    the same 2x geometry with a history length that is not a multiple of 4 -> the any-size
-    staged path. Same truth bar for all."""
+    the same 2x geometry with a history length that is not a multiple of 4 -> the staged engine, whose K = 2^15
+    transforms take the two-level path (rows of 2048 points in LDS: the smallest size that path covers, on the GPU
+    here; the other sizes in test_640k_tap_filters_take_the_two_level_path). Same truth bar for all."""
     h2 = np.fromfile(ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.bin", "<f4")
     odd = make_filter(np.concatenate([h2, np.zeros(2, np.float32)]), 131072, 131072 - 80002, 2, name="odd2x")
     for path, path_name in [(ROOT / "data" / "coefficients" / "filter_44k_2x_80000_min_phase.json", "fused"),
@@ -114,6 +115,7 @@ def test_staged_and_fused_paths_agree_at_full_size(ups, O, gpu, make_filter):
         nin, blocks = eng.in_frames, 2
         x = real_input(5, 2 * blocks * nin * 2).reshape(2, blocks * nin, 2)
         y = eng.process_host(x, blocks).view(np.float32).reshape(2, blocks * block, 2)
+        assert eng.last_two_level == (path_name == "staged")
         for s in range(2):
             for c in range(2):
                 truth = O.truth_stream(x[s, :, c], h, L, blocks, block).reshape(-1)

@@ -126,7 +126,7 @@ bool EqResponseDevice(int device, const std::string &apoText, std::size_t numBin
 struct ExpSwitches {
   bool stereoExt = false, park = false, noPhaseParts = false, noTiledInterleave = false, noRowsInterleave = false,
        noSplitPlanar = false, noTwoLevel = false, twoLevelNoPlanar = false, twoLevelStoreForward = false,
-       hostThreeStreams = false, noCoopFrames = false;
+       hostThreeStreams = false, noCoopFrames = false, forceCoopFrames = false, pitchedAnyWidth = false;
   int coopCap = 0;
   int tileTi = 0, chunkMb = 0, chunkRounds = 0, twoLevelBudgetMb = 0, hostSubBatches = 0;
   int pipeline = -1;  // 0 = never, 1 = always, -1 = by shape

@@ -767,6 +767,8 @@ ExpSwitches ExpSwitches::FromEnvironment() {
   x.twoLevelStoreForward = on("MIUPS_EXP_TWO_LEVEL_STORE_FORWARD");
   x.hostThreeStreams = on("MIUPS_EXP_HOST_THREE_STREAMS");
   x.noCoopFrames = on("MIUPS_EXP_NO_COOP_FRAMES");
+  x.forceCoopFrames = on("MIUPS_EXP_COOP_FRAMES");  // wherever a tile width fits, whatever the launch shape (tests, A/B)
+  x.pitchedAnyWidth = on("MIUPS_EXP_PITCHED_ANY_WIDTH");  // diagnostic (scripts/pitched_abort_repro.py): no host packing
   x.coopCap = num("MIUPS_EXP_COOP_CAP");
   x.tileTi = num("MIUPS_EXP_TILE_TI");
   x.chunkMb = num("MIUPS_EXP_CHUNK_MB");
@@ -1343,14 +1345,21 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     // Cooperative frames (device/frame_tile.h): the transform kernel's own workgroups assemble the frames of
     // pairs whose planes are complete while the rest of the launch computes; the frame pass behind the kernel takes what
     // is left. Needs the LDS-tiled frame form with ONE tile width that suits both the transform kernel's T threads
-    // (1..8 sixteen-byte words per thread, the tile in the workgroup's own LDS) and the 256-thread frame pass.
+    // (1, 2, 4 or 8 sixteen-byte words per thread, the tile in the workgroup's own LDS) and the 256-thread frame pass.
+    // WHERE it pays (same-box A/B, profiles/r04_b_coop_frames.txt): only where several transform workgroups share a CU
+    // (K <= 4096: a workgroup that assembles frames leaves three others computing) AND the launch is at least four
+    // full-chip rounds of workgroups long (the first round has nothing to assemble, the last round's pairs fall to the
+    // frame pass): configs[2] at 512 / 1024 / 2048 blocks +6 / +11 / +5 %, at its stated 256 blocks (two rounds) -9 %;
+    // K = 8192 (two workgroups per CU) -13 %, K = 16384 (one) -11..-13 %: there the pass alone stays.
     int coopTi = 0, coopEpt = 0;
+    const bool coopShape = wgCapacity_ >= 4 * static_cast<std::size_t>(cuCount_) &&
+                           std::min<std::size_t>(chunk, pairs) * groups_ >= 4 * wgCapacity_;  // per launch
     if (ext && !split && parts_ == 0 && !filter_->fusedNarrow() && !filter_->fusedR32() && quad && !exp_.noCoopFrames &&
-        !exp_.noTiledInterleave && exp_.pipeline != 1) {
+        !exp_.noTiledInterleave && exp_.pipeline != 1 && (coopShape || exp_.forceCoopFrames)) {
       const int rows = g.P * channels_, T = g.K / 32;
       for (int ti : {64, 32, 16}) {
         const int words = rows * (ti / 4), per = 1024 / ti;
-        const bool inKernel = T >= 64 && words % T == 0 && words / T >= 1 && words / T <= 8 &&
+        const bool inKernel = T >= 64 && words % T == 0 && (words / T == 1 || words / T == 2 || words / T == 4 || words / T == 8) &&
                               64 + static_cast<long long>(rows) * (ti + 1) * 4 <= static_cast<long long>(g.K) * 8;
         const bool framePass = rows >= 16 && rows % per == 0 && rows / per <= 8 && rows <= 512;
         if (inKernel && framePass) {
@@ -1430,7 +1439,9 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
     ioF.fsync = nullptr;
     if (coopTi) {
       const int tiles = (g.Bc + coopTi - 1) / coopTi;
-      int cap = 2 * ((tiles + groups_ - 1) / groups_);
+      // a workgroup's share of its pair's tiles and a quarter more (measured best of 8 / 12 / 16 / 26 / 52 at a share of
+      // 12.5: 16; twice the share costs 10 %: the workgroup holds registers and LDS a transform workgroup would use)
+      int cap = (5 * tiles + 4 * groups_ - 1) / (4 * groups_);
       if (exp_.coopCap > 0) {  // experiment switch (profiles/r04_*)
         cap = exp_.coopCap;
       }
@@ -1438,7 +1449,7 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
       ioF.ftile_ti = coopTi;
       ioF.ftile_ept = coopEpt;
       ioF.ftiles = tiles;
-      ioF.ftile_cap = std::max(2, (cap + 1) & ~1);
+      ioF.ftile_cap = std::max(1, cap);  // claims are whole batches of min(8, 32 / ept) tiles: a workgroup stops at or past it
     }
     hipStream_t aux = static_cast<hipStream_t>(aux_);
     std::size_t k = 0;
@@ -1710,8 +1721,8 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
   auto dwordRows = [](const void *base, std::size_t stride, std::size_t pitch, std::size_t width) {
     return reinterpret_cast<std::uintptr_t>(base) % 4 == 0 && stride % 4 == 0 && pitch % 4 == 0 && width % 4 == 0;
   };
-  const bool packIn = pitchedIn && !dwordRows(hIn, inStride, inFramePitch, inFrame);
-  const bool packOut = pitchedOut && !dwordRows(hOut, outStride, outFramePitch, outFrame);
+  const bool packIn = pitchedIn && !dwordRows(hIn, inStride, inFramePitch, inFrame) && !exp_.pitchedAnyWidth;
+  const bool packOut = pitchedOut && !dwordRows(hOut, outStride, outFramePitch, outFrame) && !exp_.pitchedAnyWidth;
   std::vector<char> hostRows;  // the fallback's packed rows of one stream and sub-batch
   // bytes one block takes in the CALLER's buffers
   const std::size_t inBlockHost = pitchedIn ? static_cast<std::size_t>(g.n_in) * inFramePitch : inBlock;
@@ -1791,6 +1802,16 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
   if (streams_ > 1 || nsub > 1) {
     lockedIn = packIn || HostRangePageLocked(hIn, inExtent);
     lockedOut = packOut || HostRangePageLocked(hOut, outExtent);
+    // A buffer whose HEAD is page-locked but whose extent is not (registered for a shorter length, a view that runs past a
+    // pinned allocation): the runtime resolves the pointer to that registration and refuses copies that run past it
+    // ("invalid argument", measured), and it cannot be registered a second time either. Say what is wrong instead.
+    if ((!lockedIn && !packIn && HostRangePageLocked(hIn, 1)) || (!lockedOut && !packOut && HostRangePageLocked(hOut, 1))) {
+      if (error) {
+        *error = "host buffer is page-locked for only part of its extent: register (mi_host_register) the whole buffer or none of it";
+      }
+      drain.armed = false;
+      return false;
+    }
     if (!lockedIn) {
       if (hipHostRegister(const_cast<void *>(hIn), inExtent, hipHostRegisterDefault) == hipSuccess) {
         pinIn.p = const_cast<void *>(hIn);

@@ -283,6 +283,25 @@ bool PrepareFilter(const CliOptions &o, int fmt, Pipeline *p) {
     }
     p->inFrames = mi_multi_in_frames_per_block(p->multi);
     p->outFrames = mi_multi_out_frames_per_block(p->multi);
+    if (o.splitChannels && o.gpus.size() > 1) {
+      // A channel group is a COLUMN of the caller's frames: it crosses the host link by pitched DMA, which moves about
+      // 180 M rows/s whatever the row width (profiles/r03_h_multi_split.txt: 64 / 32 / 16-byte rows = 11.6 / 5.7 / 2.9 GB/s
+      // against 54 GB/s for contiguous copies). Say so where the groups are narrow, and name the partition that is not.
+      std::vector<int> first(o.gpus.size() + 1, 0);
+      mi_multi_partition_channels(static_cast<int>(o.channels), static_cast<int>(o.gpus.size()), first.data());
+      size_t narrow = SIZE_MAX;
+      for (size_t i = 0; i < o.gpus.size(); ++i) {
+        if (first[i + 1] > first[i]) {
+          narrow = std::min(narrow, static_cast<size_t>(first[i + 1] - first[i]) * mi_bytes_per_sample(fmt));
+        }
+      }
+      if (narrow != SIZE_MAX && narrow < 64) {
+        std::cerr << "note: --split channels gives a GPU rows of " << narrow << " bytes; pitched DMA moves about 180 M rows/s, i.e. "
+                  << (static_cast<double>(narrow) * 0.18) << " GB/s per direction on this link against ~54 GB/s for contiguous copies. "
+                  << "For one host-fed stream --split time (contiguous block ranges per GPU) keeps the full link rate; "
+                  << "--split channels pays off for groups of 64 bytes or more, or for data that is already on the device.\n";
+      }
+    }
   } else {
     if (mi_filter_load(o.device, path, MI_LOAD_DEFAULT, &p->filter, err, sizeof(err)) != MI_OK) {
       std::cerr << "Filter load failed: " << err << "\n";
