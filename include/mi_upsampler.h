@@ -212,8 +212,9 @@ unsigned long long mi_engine_last_generation(const mi_engine *e);
  * leaves the filter usable) */
 void mi_debug_fail_next_table_upload(mi_filter *f);
 /* The rule the host-buffer paths rest on: never two asynchronous copies in flight on host ranges that are
- * not page-locked and may share a page. Every copy mi_engine_process_host / mi_multi_process_host / mi_ups_process_block
- * issues is audited against it; this returns how many broke it since the process started. Tests require 0. */
+ * not page-locked when they share a page OR are both large enough for the runtime to pin them (>= 128 KiB). Every copy
+ * mi_engine_process_host / mi_multi_process_host / mi_ups_process_block issues is audited against it; this returns how
+ * many broke it since the process started. Tests require 0. */
 unsigned long long mi_debug_unsafe_host_copies(void);
 /* test hooks: the next mi_engine_process_host (of slot `slot`'s engine for the multi form) fails right after issuing the
  * host-to-device copies of its sub-batch `sub_batch` (0-based), as if the runtime had refused a call there. The call must

@@ -570,6 +570,33 @@ def test_single_block_call_on_buffers_that_share_a_page(ups, O, gpu):
     np.testing.assert_array_equal(both[nin:], want)
 
 
+def test_one_large_copy_in_and_one_out_on_neighbouring_pageable_buffers(ups, gpu):
+    """The call shape that faulted in round 4 (profiles/r04_c_pair_fault.txt): ONE sub-batch, ONE stream -- a single copy in
+    (3.2 MB) and a single copy out (26 MB) on pageable memory, both large enough for the runtime to pin them, the two buffers
+    neighbours in the address space (carved from one mapping here; two numpy arrays mapped one after the other there). Round 3
+    left this pair alone (`a single copy per buffer cannot show it`). Now the copy in is waited for before the copy out is
+    issued: audit 0, bytes equal to the same call on page-locked buffers."""
+    path = ROOT / "data" / "coefficients" / "filter_48k_8x_160000_linear_phase.json"
+    filt = ups.Filter(path, device=gpu)
+    channels, blocks = 32, 2
+    eng = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+    ref = ups.Engine(filt, 1, channels, ups.PCM_S32, ups.PCM_S32)
+    x = synth(1, blocks * eng.in_frames, channels, seed=6)
+    nin, nout = eng.in_bytes(blocks), eng.out_bytes(blocks)
+    pin_in, pin_out = ups.PinnedBuffer(nin), ups.PinnedBuffer(nout)
+    pin_in.array[:] = x.view(np.uint8).reshape(-1)
+    want = ref.process_host(pin_in.array, blocks, out=pin_out.array).copy()
+    pad = (-nin) % 4096
+    both = np.zeros(nin + pad + nout, dtype=np.uint8)          # in | pad to a page | out: neighbours, no shared page
+    both[:nin] = x.view(np.uint8).reshape(-1)
+    before = ups.unsafe_host_copies()
+    got = eng.process_host(both[:nin], blocks, out=both[nin + pad:])
+    assert ups.unsafe_host_copies() == before
+    np.testing.assert_array_equal(got, want)
+    pin_in.close()
+    pin_out.close()
+
+
 def test_page_lock_check_covers_the_extent(ups, gpu):
     """A buffer whose HEAD is registered but whose tail is not (the caller registered a shorter length) must not be taken as
     page-locked (round 3 looked at the first byte only and would have run concurrent copies on its pageable tail). The

@@ -1634,14 +1634,24 @@ bool Engine::ProcessDevice(const void *dIn, std::size_t inStride, void *dOut, st
 namespace {
 std::atomic<unsigned long long> g_unsafeHostCopies{0};
 constexpr std::uintptr_t kHostPage = 4096;
+// From this size on the runtime may pin a pageable range for the copy instead of staging it through its own pinned buffers
+// (ROCclr GPU_PINNED_MIN_XFER_SIZE: 1 MiB by default; taken eight times lower here). Two such pins alive at once on
+// NEIGHBOURING ranges are the fault of profiles/r03_r_multi_fault.txt -- and "neighbouring" is wider than "sharing a 4 KiB
+// page": round 4 met it on the one path round 3 had left alone, ONE copy in and ONE copy out (3.2 MB and 26 MB, two numpy
+// arrays mapped one after the other, profiles/r04_c_pair_fault.txt). So two large copies on memory that is not page-locked
+// are never in flight together, wherever they are.
+constexpr std::size_t kRuntimePinsFrom = 128 * 1024;
 
 struct PageSpan {
   std::uintptr_t lo, hi;  // first and last page-aligned address touched
+  std::size_t bytes;
   bool touches(const PageSpan &o) const { return lo <= o.hi && o.lo <= hi; }
+  // may not be in flight together when neither is page-locked
+  bool conflicts(const PageSpan &o) const { return touches(o) || (bytes >= kRuntimePinsFrom && o.bytes >= kRuntimePinsFrom); }
 };
 PageSpan SpanOf(const void *p, std::size_t bytes) {
   const std::uintptr_t a = reinterpret_cast<std::uintptr_t>(p);
-  return PageSpan{a & ~(kHostPage - 1), (a + (bytes ? bytes - 1 : 0)) & ~(kHostPage - 1)};
+  return PageSpan{a & ~(kHostPage - 1), (a + (bytes ? bytes - 1 : 0)) & ~(kHostPage - 1), bytes};
 }
 
 class HostCopyAudit {
@@ -1654,7 +1664,7 @@ class HostCopyAudit {
     const PageSpan sp = SpanOf(host, bytes);
     for (const auto &v : open_) {
       for (const PageSpan &o : v) {
-        if (sp.touches(o)) {
+        if (sp.conflicts(o)) {
           g_unsafeHostCopies.fetch_add(1, std::memory_order_relaxed);
         }
       }
@@ -1830,10 +1840,11 @@ bool Engine::ProcessHost(const void *hIn, std::size_t inStride, void *hOut, std:
         serialCopies = true;
       }
     }
-  } else if (!packIn && !packOut && SpanOf(hIn, inExtent).touches(SpanOf(hOut, outExtent))) {
-    // One copy in and one copy out (the reference's call shape, mi_ups_process_block): the pair itself is two copies, and
-    // heap neighbours share a page. Only then ask the runtime (two attribute queries stay off the 69 us path otherwise);
-    // unless both ends are page-locked the copy in is waited for before the copy out is issued.
+  } else if (!packIn && !packOut && SpanOf(hIn, inExtent).conflicts(SpanOf(hOut, outExtent))) {
+    // One copy in and one copy out (the reference's call shape, mi_ups_process_block): the pair itself is two copies. They
+    // conflict when they share a page (heap neighbours do) or when both are large enough for the runtime to pin them.
+    // Only then ask the runtime (two attribute queries stay off the 69 us path of a one-channel block: 51 KB in, 204 KB
+    // out, separate pages); unless both ends are page-locked the copy in is waited for before the copy out is issued.
     lockedIn = HostRangePageLocked(hIn, inExtent);
     lockedOut = HostRangePageLocked(hOut, outExtent);
     waitBetween = !(lockedIn && lockedOut);
