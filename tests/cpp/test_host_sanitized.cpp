@@ -93,6 +93,18 @@ int main(int argc, char **argv) {
       std::vector<double> resp(2 * 257), mag(257);
       mi_eq_response_host(text.c_str(), 257, 512, 705600.0, resp.data());
       mi_eq_magnitude_host(text.c_str(), 257, 512, 705600.0, mag.data());
+      // the EQ folded into a FIR (recursion over the taps, free decay followed to the work cap at most): whatever the
+      // profile holds -- unstable sections, zero or absurd Q, frequencies beyond Nyquist -- it must come back
+      std::vector<float> taps(300);
+      for (size_t i = 0; i < taps.size(); ++i) {
+        taps[i] = static_cast<float>((static_cast<int>(i * 37u % 101u) - 50)) * 0.01f;
+      }
+      std::vector<double> fir(taps.size());
+      mi_eq_residual res;
+      if (mi_eq_fold_host(taps.data(), taps.size(), 512, text.c_str(), 705600.0, fir.data(), &res) != MI_OK) {
+        std::printf("mi_eq_fold_host refused %s\n", name.c_str());
+        return 1;
+      }
     } else if (name.rfind("sidecar_", 0) == 0 && name.size() > 5 && name.compare(name.size() - 5, 5, ".json") == 0) {
       mi_ups_config c;
       accepted += mi_read_filter(path.c_str(), &c, err, sizeof(err)) == MI_OK;
