@@ -59,4 +59,10 @@ if [ $part = 3 ]; then
   PMC_GROUPS=("${ISSUE_GROUPS[@]}")
   pmc issue_c2_256 --no-extras --config 2
 fi
+if [ $part = 4 ]; then  # issue-side SQ counters of the transform kernels of configs 3-5 (what bounds them: roofline.compute)
+  PMC_GROUPS=("${ISSUE_GROUPS[@]}")
+  pmc issue_c3 --no-extras --config 3
+  pmc issue_c4 --no-extras --config 4
+  pmc issue_c5 --no-extras --config 5
+fi
 exit 0

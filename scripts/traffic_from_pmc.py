@@ -59,14 +59,16 @@ def main():
         res[key] = {"streams": streams, "channels": channels, "blocks": blocks, "bytes": int(total), "kernels": kernels,
                     "source": f"profiles/{PREFIX}_pmc_{tag}.txt"}
         (ROOT / "profiles" / f"{PREFIX}_pmc_{tag}.txt").write_text((SRC / f"pmc_{tag}.txt").read_text())
-    issue = SRC / "pmc_issue_c2_256.txt"
-    if issue.exists():
-        # issue side of the headline's kernel (SQ counters, per launch; SQ cycle counters tick once per 4 clocks)
+    # issue side of each config's TRANSFORM kernel (SQ counters, per launch; SQ cycle counters tick once per 4 clocks)
+    for itag, key in (("issue_c2_256", "2"), ("issue_c3", "3"), ("issue_c4", "4"), ("issue_c5", "5")):
+        issue = SRC / f"pmc_{itag}.txt"
+        if not issue.exists() or key not in res:
+            continue
         k = parse(issue)
-        name = next(n for n in k if "fused_kernel" in n)
+        name = next(n for n in k if "fused_kernel" in n or "fused_split_kernel" in n)
         c = {n: v[0] for n, v in k[name].items()}
         waves = c["SQ_WAVES"]
-        res["2"]["issue"] = {
+        res[key]["issue"] = {
             "kernel": name, "waves": int(waves), "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / waves, 1),
             "lds_insts_per_wave": round(c["SQ_INSTS_LDS"] / waves, 1), "salu_insts_per_wave": round(c["SQ_INSTS_SALU"] / waves, 1),
             "vmem_rd_insts_per_wave": round(c["SQ_INSTS_VMEM_RD"] / waves, 1),
@@ -75,8 +77,8 @@ def main():
             "wait_inst_any_share_of_wave_clocks": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3),
             "wait_inst_lds_share_of_wave_clocks": round(c["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"], 3),
             "lds_bank_conflict_share_of_lds_active": round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 4),
-            "source": f"profiles/{PREFIX}_pmc_issue_c2_256.txt"}
-        (ROOT / "profiles" / f"{PREFIX}_pmc_issue_c2_256.txt").write_text(issue.read_text())
+            "source": f"profiles/{PREFIX}_pmc_{itag}.txt"}
+        (ROOT / "profiles" / f"{PREFIX}_pmc_{itag}.txt").write_text(issue.read_text())
     (ROOT / "profiles" / "traffic.json").write_text(json.dumps(res, indent=1) + "\n")
     for key, v in res.items():
         if key != "_comment":
