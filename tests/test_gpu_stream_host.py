@@ -145,6 +145,27 @@ def test_multi_engine_eq_change_is_all_or_nothing(ups, gpu):
     assert all((eqd[s] != plain.reshape(streams, -1)[s]).any() for s in range(streams))
 
 
+def test_multi_engine_reports_and_refuses_an_eq_that_does_not_fit(ups, gpu):
+    """The EQ fold's residual through the multi-GPU object: every slot folds the same taps, the report is slot 0's; over the
+    limit the change goes through with a warning -- or, strict, is refused as a whole (MI_ERR_FILTER text) with no slot changed."""
+    streams, channels, blocks = 2, 2, 2
+    multi = ups.MultiEngine(F4X, [0, 0], streams, channels)
+    x = synth(streams, blocks * multi.in_frames, channels, seed=6)
+    plain = multi.process_host(x, blocks).copy()
+    assert multi.eq_residual()["active"] == 0
+    low = "Filter 1: ON PK Fc 20 Hz Gain 6 dB Q 8\n"
+    w = multi.set_eq(low, 705600.0)
+    r = multi.eq_residual()
+    assert w.startswith("EQ cut to 80001 taps drops ") and r["over_limit"] == 1 and r["active"] == 1 and r["tail_l1"] > 1e-2
+    multi.set_eq("", 705600.0)
+    multi.set_eq_limit(-1.0, strict=True)
+    with pytest.raises(ups.UpsamplerError, match="EQ cut to 80001 taps drops .* no slot was changed"):
+        multi.set_eq(low, 705600.0)
+    multi.reset()
+    np.testing.assert_array_equal(multi.process_host(x, blocks), plain)
+    assert multi.set_eq(PROFILES["opra10"], 705600.0) == "" and multi.eq_residual()["over_limit"] == 0
+
+
 def test_multi_engine_refuses_devices_that_are_not_there(ups, gpu):
     n = ups.device_count()
     with pytest.raises(ups.UpsamplerError, match=f"device {n} requested but only {n} HIP device"):
